@@ -1,0 +1,92 @@
+"""ORACLE (test infrastructure) — ctypes binding of oracle/libsicn_oracle.so (sicn_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this."""
+from __future__ import annotations
+
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+
+class OrDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "K", "S", "P", "IFM_CH", "IFM_ROW", "IFM_COL", "OFM_CH", "OFM_ROW", "OFM_COL",
+        "SIMD", "PE", "IN_BIT", "OUT_BIT", "W_BIT", "W_TILES", "transposed")]
+
+
+def build(force: bool = False) -> Path:
+    so = _HERE / "libsicn_oracle.so"
+    src = _HERE / "sicn_oracle.c"
+    if force or not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["make", "-C", str(_HERE), "-B", "libsicn_oracle.so"], check=True,
+                       capture_output=True)
+    return so
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(str(build()))
+        p = ctypes.c_void_p
+        for name in ("sicn_or_conv2d_dataflow", "sicn_or_deconv522_dataflow"):
+            getattr(L, name).argtypes = [ctypes.POINTER(OrDesc), p, p, p, p, ctypes.c_int]
+            getattr(L, name).restype = ctypes.c_int
+        for name in ("sicn_or_naive_conv2d", "sicn_or_naive_deconv2d"):
+            getattr(L, name).argtypes = [ctypes.POINTER(OrDesc), p, p, p, p]
+            getattr(L, name).restype = ctypes.c_int
+        L.sicn_or_layer_direct.argtypes = [ctypes.POINTER(OrDesc), p, p, p, p, ctypes.c_int]
+        L.sicn_or_layer_direct.restype = ctypes.c_int
+        L.sicn_or_swg_nonsquare_fsm.argtypes = [p, ctypes.c_longlong, p] + [ctypes.c_int] * 10
+        L.sicn_or_swg_nonsquare_fsm.restype = ctypes.c_longlong
+        L.sicn_or_im2col_s1.argtypes = [p, p] + [ctypes.c_int] * 5
+        L.sicn_or_im2col_s1.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _desc(d) -> OrDesc:
+    return OrDesc(**{n: int(getattr(d, n)) for n, _ in OrDesc._fields_})
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def run_layer(d, words: np.ndarray, bias: np.ndarray, x: np.ndarray, form: str = "dataflow",
+              threads: int = 1) -> np.ndarray:
+    """Run one layer through the C oracle. form: 'dataflow' (FSM sliding window), 'dataflow_im2col',
+    'naive' (the reference testbench's golden model) or 'direct' (closed form)."""
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    bias = np.ascontiguousarray(bias, dtype=np.int8)
+    x = np.ascontiguousarray(x, dtype=np.uint8)
+    assert x.shape == (d.IFM_COL, d.IFM_ROW, d.IFM_CH), (x.shape, d)
+    assert words.shape == (d.PE, d.W_TILES) and bias.shape == (d.OFM_CH,)
+    out = np.empty((d.OFM_COL, d.OFM_ROW, d.OFM_CH), dtype=np.uint8)
+    cd = _desc(d)
+    L = lib()
+    if form in ("dataflow", "dataflow_im2col"):
+        fn = L.sicn_or_deconv522_dataflow if d.transposed else L.sicn_or_conv2d_dataflow
+        rc = fn(ctypes.byref(cd), _ptr(words), _ptr(bias), _ptr(x), _ptr(out), int(form == "dataflow"))
+    elif form == "naive":
+        fn = L.sicn_or_naive_deconv2d if d.transposed else L.sicn_or_naive_conv2d
+        rc = fn(ctypes.byref(cd), _ptr(words), _ptr(bias), _ptr(x), _ptr(out))
+    elif form == "direct":
+        rc = L.sicn_or_layer_direct(ctypes.byref(cd), _ptr(words), _ptr(bias), _ptr(x), _ptr(out), threads)
+    else:
+        raise ValueError(form)
+    if rc != 0:
+        raise RuntimeError(f"oracle {form} failed rc={rc}")
+    return out
+
+
+def run_net(descs, words_list, bias_list, x: np.ndarray, form: str = "dataflow", threads: int = 1):
+    outs = []
+    for d, w, b in zip(descs, words_list, bias_list):
+        x = run_layer(d, w, b, x, form, threads)
+        outs.append(x)
+    return outs

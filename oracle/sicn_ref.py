@@ -1,0 +1,145 @@
+"""ORACLE (test infrastructure, NOT product code) — numpy closed-form restatement of the
+reference's conv/deconv transform path.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+module; the product path (`simple_image_compression_network_amd/`) never does.
+
+Pinning status: the reference itself cannot be built here (it needs Xilinx Vivado-HLS 2020.1
+headers `ap_int.h` / `hls_stream.h` / `ap_axi_sdata.h`, README:5, which are neither vendored nor
+installed, and no stand-ins are written).  This restatement is pinned against the 24 SHA-256
+known-answer vectors of SURVEY.md Appendix A (all 8 layer outputs for three inputs, produced by
+the reference's own `conv2d<>` / `deconv522<>` templates during the survey) — see
+tests/test_oracle_golden.py — and against the reference's own self-check logic (dataflow ==
+naive golden, conv3_nonsquare_tb.cpp:1068-1104), restated in oracle/sicn_oracle.c.
+
+Each function cites the reference lines it follows.  Tensors are row-major `[H][W][C] uint8`
+(byte-identical to the reference's `hls::stream<ap_uint<C*8>>`, channel c in bits [8c,8c+8),
+conv3_nonsquare_tb.cpp:807-808,1080).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+K5 = 5
+
+
+# ------------------------------------------------------------------------------------------
+# Weight wire format: FixedPointWeights<SIMD, ap_int<4>, PE, TILES>  (weights.hpp:110-150)
+# ------------------------------------------------------------------------------------------
+def unpack_finn_tiles(words: np.ndarray, simd: int, pe: int, cin: int, cout: int) -> np.ndarray:
+    """m_weights[PE][TILES] words -> W[o][ky][kx][c] int8.
+
+    weights.hpp:134-139: element `s` of tile word t is the sign-extended nibble in bits
+    [4s, 4s+4).  mvau.hpp:149-156 with invariant tile = nf*SF + sf (mvau.hpp:118): output
+    channel o = nf*PE + pe, K index k = sf*SIMD + s.  The sliding-window generator emits
+    ky -> kx -> channel-chunk order (slidingwindow.h:1304-1325), so k = (ky*5+kx)*Cin + c;
+    cross-checked by the testbench's own unpack loop (conv3_nonsquare_tb.cpp:546-571).
+    """
+    words = np.asarray(words, dtype=np.uint64)
+    kk = K5 * K5 * cin
+    sf_n, nf_n = kk // simd, cout // pe
+    assert words.shape == (pe, nf_n * sf_n), (words.shape, pe, nf_n, sf_n)
+    shifts = (np.arange(simd, dtype=np.uint64) * np.uint64(4))
+    nib = ((words[:, :, None] >> shifts[None, None, :]) & np.uint64(15)).astype(np.int16)
+    nib = np.where(nib > 7, nib - 16, nib).astype(np.int8)           # [pe][tile][s]
+    nib = nib.reshape(pe, nf_n, sf_n * simd)                         # [pe][nf][k]
+    w = nib.transpose(1, 0, 2).reshape(cout, K5, K5, cin)            # o = nf*PE + pe
+    return np.ascontiguousarray(w)
+
+
+def pack_finn_tiles(w: np.ndarray, simd: int, pe: int) -> np.ndarray:
+    """Inverse of `unpack_finn_tiles`: W[o][ky][kx][c] int4-valued -> uint64 words [PE][TILES]."""
+    cout, _, _, cin = w.shape
+    kk = K5 * K5 * cin
+    sf_n, nf_n = kk // simd, cout // pe
+    assert w.min() >= -8 and w.max() <= 7
+    nib = (w.reshape(nf_n, pe, sf_n, simd).astype(np.int16) & 15).astype(np.uint64)
+    shifts = (np.arange(simd, dtype=np.uint64) * np.uint64(4))
+    words = (nib << shifts[None, None, None, :]).sum(axis=3, dtype=np.uint64)   # [nf][pe][sf]
+    return np.ascontiguousarray(words.transpose(1, 0, 2).reshape(pe, nf_n * sf_n))
+
+
+# ------------------------------------------------------------------------------------------
+# Closed forms of SURVEY.md §8(a) rows a8 / a9
+# ------------------------------------------------------------------------------------------
+def _exact_gemm_ok(k: int, xmax: int) -> None:
+    # float32 sums of integers stay exact while every partial sum is < 2^24
+    assert k * xmax * 8 < (1 << 24), "fp32 accumulation would not be exact"
+
+
+def _bias_relu_wrap8(acc: np.ndarray, bias: np.ndarray) -> np.ndarray:
+    """conv_nonsquare_top.cpp:267-278 / 183-194: lane = (lane + bias) mod 2^8; MSB set -> 0.
+    The MVAU accumulator is ap_uint<8> (mvau.hpp:112 with activations.hpp:112-115,127-134), so
+    every `+=` of mac.hpp:166-169 wraps mod 256; computing wide and truncating once is the same
+    ring homomorphism."""
+    v = (acc.astype(np.int64) + bias.astype(np.int64)[None, None, :]) & 0xFF
+    v[v >= 128] = 0
+    return v.astype(np.uint8)
+
+
+def _conv_taps(xpad: np.ndarray, w: np.ndarray, oh: int, ow: int, stride: int) -> np.ndarray:
+    """sum_{ky,kx,c} xpad[stride*y+ky][stride*x+kx][c] * W[o][ky][kx][c]  -> int64 [oh][ow][o]."""
+    cout, _, _, cin = w.shape
+    _exact_gemm_ok(25 * cin, int(xpad.max()) if xpad.size else 0)
+    acc = np.zeros((oh * ow, cout), dtype=np.float32)
+    xf = xpad.astype(np.float32)
+    wf = w.astype(np.float32)
+    for ky in range(K5):
+        for kx in range(K5):
+            a = xf[ky:ky + stride * (oh - 1) + 1:stride, kx:kx + stride * (ow - 1) + 1:stride, :]
+            acc += a.reshape(oh * ow, cin) @ wf[:, ky, kx, :].T
+    return np.rint(acc).astype(np.int64).reshape(oh, ow, cout)
+
+
+def conv2d_ref(x: np.ndarray, w: np.ndarray, bias: np.ndarray) -> np.ndarray:
+    """`conv2d<>` (conv_nonsquare_top.cpp:198-280): 2-pixel zero border (padding2 ->
+    FMPadding_nonsquare, top:59-69, streamtools.h:369-406), stride-1 im2col
+    (slidingwindow.h:1254-1353) decimated to even rows/cols (top:243-259), MVAU, bias+ReLU.
+    out[y][x][o] = relu7((sum xpad[2y+ky][2x+kx][c] W[o][ky][kx][c] + b[o]) mod 256)."""
+    h, wd, _ = x.shape
+    oh, ow = (h + 1) // 2, (wd + 1) // 2
+    xpad = np.pad(x, ((2, 2), (2, 2), (0, 0)))
+    return _bias_relu_wrap8(_conv_taps(xpad, w, oh, ow, 2), bias)
+
+
+def zero_stuff_pad(x: np.ndarray) -> np.ndarray:
+    """deconv522 input staging (conv_nonsquare_top.cpp:110-156): zero-insert to (2H-1)x(2W-1),
+    one zero column right / row bottom, then 2-pixel border: Up_pad[2i+2][2j+2] = x[i][j]."""
+    h, wd, c = x.shape
+    up = np.zeros((2 * h + 4, 2 * wd + 4, c), dtype=x.dtype)
+    up[2:2 + 2 * h:2, 2:2 + 2 * wd:2, :] = x
+    return up
+
+
+def deconv522_ref(x: np.ndarray, w: np.ndarray, bias: np.ndarray) -> np.ndarray:
+    """`deconv522<>` (conv_nonsquare_top.cpp:71-195): stride-1 5x5 conv over the zero-stuffed,
+    padded map, kernel NOT flipped; out is 2H x 2W."""
+    h, wd, _ = x.shape
+    return _bias_relu_wrap8(_conv_taps(zero_stuff_pad(x), w, 2 * h, 2 * wd, 1), bias)
+
+
+Params = Sequence[Tuple[np.ndarray, np.ndarray, int]]   # (W[o][ky][kx][c], bias[o], transposed)
+
+
+def eight_layers_net_ref(x: np.ndarray, params: Params) -> List[np.ndarray]:
+    """`eight_layers_net` (conv_nonsquare_top.cpp:295-357): returns every layer output."""
+    outs = []
+    for w, b, transposed in params:
+        x = deconv522_ref(x, w, b) if transposed else conv2d_ref(x, w, b)
+        outs.append(x)
+    return outs
+
+
+def load_param_fixture(path) -> List[Tuple[np.ndarray, np.ndarray, int]]:
+    """tests/golden/param_weights.npz -> [(W, bias, transposed)] for the 8 reference layers."""
+    z = np.load(path)
+    chans = ((3, 128, 0), (128, 128, 0), (128, 128, 0), (128, 192, 0),
+             (192, 128, 1), (128, 128, 1), (128, 128, 1), (128, 3, 1))
+    out = []
+    for n, (cin, cout, tr) in enumerate(chans):
+        simd, wbit, pe, tiles = (int(v) for v in z[f"w{n}_meta"])
+        assert wbit == 4 and tiles == (cout // pe) * (25 * cin // simd)
+        out.append((unpack_finn_tiles(z[f"w{n}_words"], simd, pe, cin, cout), z[f"b{n}"].copy(), tr))
+    return out
