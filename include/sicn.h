@@ -1,0 +1,137 @@
+/*
+ * sicn.h — C ABI of libsicn.so, the MI355X (gfx950) implementation of the integer conv/deconv
+ * transform path of shengjie-chen/simple_image_compression_network.
+ *
+ * Every entry point replaces one piece of the reference's HLS interface (paths relative to the
+ * reference tree):
+ *
+ *   sicn_conv2d            <- template conv2d<...>(weights, bias, in, out, numReps)
+ *                             conv_nonsquare_top.cpp:198-280; conv2d_layer0, :282-286
+ *   sicn_deconv522         <- template deconv522<...>(weights, bias, in, out, numReps)
+ *                             conv_nonsquare_top.cpp:71-195; deconv2d_layer4, :288-291
+ *   sicn_eight_layers_net  <- eight_layers_net(in, out, numReps), conv_nonsquare_top.cpp:295-357
+ *   sicn_weights_from_finn_tiles
+ *                          <- FixedPointWeights<SIMD, ap_int<4>, PE, TILES>::m_weights[PE][TILES]
+ *                             weights.hpp:110-150 and the bias table
+ *                             FixedPointWeights<1, ap_int<8>, 1, OFM_CH> (memdata_nonsquare.h:16)
+ *   sicn_layer_desc        <- the CONV_n_* macro set, config_nonsquare.h:2-16
+ *
+ * Data model.  An `hls::stream<ap_uint<C*8>>` carrying H*W words (channel c in bits [8c,8c+8),
+ * conv3_nonsquare_tb.cpp:807-808) is byte-identical to a row-major [H][W][C] uint8 array; that
+ * array, in DEVICE memory, is the only tensor format of this ABI.  `n_images` images are
+ * concatenated ([n][H][W][C]).  The reference's `numReps` is only meaningful at 1
+ * (conv_nonsquare_top.cpp:111,133,184,246,268 iterate one image); `n_images` here is a true batch
+ * of independent single-image reference calls.
+ *
+ * Numerics: bit-exact with the HLS C-simulation.  The MVAU accumulator is ap_uint<8>
+ * (mvau.hpp:112, activations.hpp:112-115,127-134) so results are defined mod 2^8:
+ *   out = relu7((sum_k in[k]*W[o][k] + bias[o]) mod 256),  relu7(v) = v >= 128 ? 0 : v.
+ *
+ * Conventions: all functions return 0 or a negative errno-style code (never exit(), never throw —
+ * the reference's CASSERT_DATAFLOW exit(-1), bnn-library.h:55, becomes SICN_EINVAL).  Buffers are
+ * owned by the caller; the library never frees caller memory.  Entry points that take a
+ * `hip_stream` only enqueue work on that hipStream_t (NULL = default stream) and perform no
+ * allocation or synchronisation, so they can be captured into a hipGraph.  Handles are immutable
+ * after creation; concurrent launches on different streams are allowed provided each uses its own
+ * workspace.
+ *
+ * Naming trap inherited from the reference: IFM_ROW / OFM_ROW are WIDTHS (x, fast dimension),
+ * IFM_COL / OFM_COL are HEIGHTS (conv_nonsquare_top.cpp:283-285).
+ */
+#ifndef SICN_H
+#define SICN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SICN_OK 0
+#define SICN_EINVAL (-22)   /* bad descriptor / argument (reference: CASSERT_DATAFLOW)          */
+#define SICN_ENOMEM (-12)   /* host or device allocation failed                                */
+#define SICN_ENODEV (-19)   /* no usable gfx950 device / HIP runtime error at launch           */
+#define SICN_ENOSPC (-28)   /* caller-provided workspace too small                             */
+
+/* config_nonsquare.h:2-16, one struct per layer, plus which template the layer instantiates. */
+typedef struct sicn_layer_desc {
+    int32_t K;          /* CONV_n_K        kernel size, must be 5                               */
+    int32_t S;          /* CONV_n_S        stride, must be 2                                    */
+    int32_t P;          /* CONV_n_P        padding, must be 2                                   */
+    int32_t IFM_CH;     /* CONV_n_IFM_CH   input channels                                       */
+    int32_t IFM_ROW;    /* CONV_n_IFM_ROW  input WIDTH                                          */
+    int32_t IFM_COL;    /* CONV_n_IFM_COL  input HEIGHT                                         */
+    int32_t OFM_CH;     /* CONV_n_OFM_CH   output channels                                      */
+    int32_t OFM_ROW;    /* CONV_n_OFM_ROW  output WIDTH  (conv: ceil(in/2); deconv: 2*in)       */
+    int32_t OFM_COL;    /* CONV_n_OFM_COL  output HEIGHT                                        */
+    int32_t SIMD;       /* CONV_n_SIMD     input lanes per weight word (wire format only)       */
+    int32_t PE;         /* CONV_n_PE       output lanes per weight tile (wire format only)      */
+    int32_t IN_BIT;     /* CONV_n_IN_BIT   must be 8                                            */
+    int32_t OUT_BIT;    /* CONV_n_OUT_BIT  must be 8                                            */
+    int32_t W_BIT;      /* CONV_n_W_BIT    must be 4                                            */
+    int32_t W_TILES;    /* CONV_n_W_TILES  = (OFM_CH/PE) * (25*IFM_CH/SIMD)                     */
+    int32_t transposed; /* 0: conv2d<> ; 1: deconv522<>                                         */
+} sicn_layer_desc;
+
+typedef struct sicn_weights sicn_weights; /* one layer's weights+bias, resident on the device  */
+typedef struct sicn_net sicn_net;         /* a chain of layers (the 8-layer net, or any chain) */
+
+/* Library / device ------------------------------------------------------------------------- */
+int sicn_version(void);                  /* 1000*major + minor                                 */
+const char *sicn_strerror(int code);
+int sicn_validate_desc(const sicn_layer_desc *desc); /* pure host check, no GPU needed         */
+
+/* Weights ---------------------------------------------------------------------------------- */
+/* Ingests the reference wire format verbatim.  `m_weights` = HOST array [PE][W_TILES] of words
+ * holding SIMD nibbles (element s in bits [4s,4s+4), weights.hpp:134-139), each word stored in
+ * `word_bytes` (1,2,4 or 8) little-endian bytes; `bias` = HOST int8[OFM_CH].  Only desc fields
+ * IFM_CH, OFM_CH, SIMD, PE, W_TILES, transposed are used (weights do not depend on image size).
+ * Synchronous (uploads to the current device). */
+int sicn_weights_from_finn_tiles(const sicn_layer_desc *desc, const void *m_weights, int word_bytes,
+                                 const int8_t *bias, sicn_weights **out);
+void sicn_weights_free(sicn_weights *w);
+
+/* Single layers ---------------------------------------------------------------------------- */
+/* in_nhwc : DEVICE [n_images][IFM_COL][IFM_ROW][IFM_CH] uint8
+ * out_nhwc: DEVICE [n_images][OFM_COL][OFM_ROW][OFM_CH] uint8 (values 0..127)                  */
+int sicn_conv2d(const sicn_layer_desc *desc, const sicn_weights *w, const uint8_t *in_nhwc,
+                uint8_t *out_nhwc, int n_images, void *hip_stream);
+int sicn_deconv522(const sicn_layer_desc *desc, const sicn_weights *w, const uint8_t *in_nhwc,
+                   uint8_t *out_nhwc, int n_images, void *hip_stream);
+/* Name of the kernel family that will serve `desc` ("l0_rgb", "mfma_conv", "mfma_deconv",
+ * "l7_rgb", "generic"); static string. */
+const char *sicn_kernel_for(const sicn_layer_desc *desc);
+/* Force the shape-agnostic kernel for every layer (testing aid; default 0). Process-wide. */
+void sicn_set_force_generic(int on);
+
+/* Layer chains ----------------------------------------------------------------------------- */
+/* descs[i+1] input dims/channels must equal descs[i] output dims/channels.  The net keeps
+ * references to `weights` (caller keeps them alive). */
+int sicn_net_create(const sicn_layer_desc *descs, sicn_weights *const *weights, int n_layers,
+                    sicn_net **out);
+void sicn_net_free(sicn_net *net);
+/* Bytes of DEVICE scratch `sicn_net_forward` needs for a batch of n_images. */
+size_t sicn_net_workspace_bytes(const sicn_net *net, int n_images);
+/* Runs layers [first_layer, last_layer] of the chain.  `tap_layer` >= 0 additionally copies that
+ * layer's output (e.g. 3 = the latent, conv_3_out, conv_nonsquare_top.cpp:322-325) to `tap_out`. */
+int sicn_net_forward(const sicn_net *net, int first_layer, int last_layer, const uint8_t *in,
+                     uint8_t *out, int tap_layer, uint8_t *tap_out, int n_images, void *workspace,
+                     size_t workspace_bytes, void *hip_stream);
+/* eight_layers_net(in, out, numReps): the whole chain; latent_or_null receives layer 3's output. */
+int sicn_eight_layers_net(const sicn_net *net, const uint8_t *in, uint8_t *out,
+                          uint8_t *latent_or_null, int n_images, void *workspace,
+                          size_t workspace_bytes, void *hip_stream);
+
+/* Per-layer device timing (measurement aid) ------------------------------------------------ */
+/* When enabled, sicn_net_forward brackets every layer launch with hipEvents on the launch stream.
+ * sicn_net_layer_ms synchronises on the last recorded events and returns, per layer, the SUM of
+ * milliseconds and the number of launches since the last reset. */
+int sicn_net_profile(sicn_net *net, int enable);
+int sicn_net_layer_ms(sicn_net *net, int reset, float *ms_sum /*[n_layers]*/,
+                      int *launches /*[n_layers]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SICN_H */

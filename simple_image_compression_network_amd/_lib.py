@@ -1,0 +1,66 @@
+"""ctypes loader for libsicn.so (the HIP implementation behind include/sicn.h).
+
+There is no CPU fallback: if the shared library is missing or does not export a symbol of
+include/sicn.h this module raises, loudly, at import of the first entry point that needs it."""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+from .config import CLayerDesc
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("SICN_LIB", _PKG / "libsicn.so"))
+
+# every symbol include/sicn.h declares: (restype, argtypes)
+_vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+_descp = ctypes.POINTER(CLayerDesc)
+ABI = {
+    "sicn_version": (_i, []),
+    "sicn_strerror": (ctypes.c_char_p, [_i]),
+    "sicn_validate_desc": (_i, [_descp]),
+    "sicn_weights_from_finn_tiles": (_i, [_descp, _vp, _i, _vp, ctypes.POINTER(_vp)]),
+    "sicn_weights_free": (None, [_vp]),
+    "sicn_conv2d": (_i, [_descp, _vp, _vp, _vp, _i, _vp]),
+    "sicn_deconv522": (_i, [_descp, _vp, _vp, _vp, _i, _vp]),
+    "sicn_kernel_for": (ctypes.c_char_p, [_descp]),
+    "sicn_set_force_generic": (None, [_i]),
+    "sicn_net_create": (_i, [_descp, ctypes.POINTER(_vp), _i, ctypes.POINTER(_vp)]),
+    "sicn_net_free": (None, [_vp]),
+    "sicn_net_workspace_bytes": (_sz, [_vp, _i]),
+    "sicn_net_forward": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    "sicn_eight_layers_net": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "sicn_net_profile": (_i, [_vp, _i]),
+    "sicn_net_layer_ms": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]),
+}
+
+_lib = None
+
+
+class SicnError(RuntimeError):
+    def __init__(self, code: int, what: str):
+        self.code = code
+        msg = lib().sicn_strerror(code).decode() if _lib is not None else "?"
+        super().__init__(f"{what}: {msg} ({code})")
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(
+                f"{LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C {_PKG / 'csrc'}`; there is no non-HIP fallback")
+        L = ctypes.CDLL(str(LIB_PATH))
+        for name, (res, args) in ABI.items():
+            fn = getattr(L, name)          # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise SicnError(code, what)

@@ -1,0 +1,60 @@
+// Shape-agnostic conv2d<> / deconv522<> (any IFM_CH / OFM_CH / image size): one thread per output
+// byte, direct evaluation of the closed forms of SURVEY.md §8(a) a8/a9.  It serves layer shapes the
+// specialised kernels do not cover (and the force-generic testing switch); it is a HIP kernel like
+// the others — there is no CPU fallback anywhere in this library.
+//
+//   conv   (conv_nonsquare_top.cpp:198-280): out[y][x][o] = relu7((sum in[2y+ky-2][2x+kx-2][c] W + b) mod 256)
+//   deconv (conv_nonsquare_top.cpp:71-195) : out[y][x][o] = relu7((sum Up[y+ky-2][x+kx-2][c] W + b) mod 256),
+//                                            Up[2i][2j] = in[i][j], zero elsewhere (kernel not flipped)
+#include "sicn_internal.h"
+
+namespace sicn {
+
+__global__ __launch_bounds__(256) void k_generic(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                 const int8_t *__restrict__ w_okc,
+                                                 const int8_t *__restrict__ bias, int IW, int IH, int C,
+                                                 int OW, int OH, int N, int transposed)
+{
+    const size_t total = (size_t)OH * OW * N;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int img = blockIdx.y;
+    const int o = (int)(idx % N);
+    const size_t pix = idx / N;
+    const int x = (int)(pix % OW), y = (int)(pix / OW);
+    const uint8_t *im = in + (size_t)img * IH * IW * C;
+    const int8_t *wo = w_okc + (size_t)o * 25 * C;
+    int acc = bias[o];
+    for (int ky = 0; ky < 5; ky++)
+        for (int kx = 0; kx < 5; kx++) {
+            int iy, ix;
+            if (transposed) {
+                const int py = y + ky - 2, px = x + kx - 2;
+                if ((py & 1) || (px & 1)) continue;
+                iy = py >> 1;
+                ix = px >> 1;
+            } else {
+                iy = 2 * y + ky - 2;
+                ix = 2 * x + kx - 2;
+            }
+            if (iy < 0 || iy >= IH || ix < 0 || ix >= IW) continue;
+            const uint8_t *s = im + ((size_t)iy * IW + ix) * C;
+            const int8_t *wk = wo + (ky * 5 + kx) * C;
+            for (int c = 0; c < C; c++) acc += (int)s[c] * (int)wk[c];
+        }
+    const int v = acc & 0xFF;
+    out[(size_t)img * total + idx] = (uint8_t)((v & 0x80) ? 0 : v);
+}
+
+hipError_t launch_generic(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
+                          int n_images, hipStream_t stream)
+{
+    const size_t total = (size_t)g.OH * g.OW * g.COUT;
+    const size_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffu) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_generic, dim3((unsigned)blocks, (unsigned)n_images), dim3(256), 0, stream, in, out,
+                       w.d_w_okc, w.d_bias, g.IW, g.IH, g.CIN, g.OW, g.OH, g.COUT, g.transposed);
+    return hipGetLastError();
+}
+
+}  // namespace sicn

@@ -1,0 +1,360 @@
+// libsicn.so — C ABI (include/sicn.h): descriptor validation, weight ingestion from the
+// reference's FixedPointWeights tile format, kernel dispatch, layer chains with caller-provided
+// workspace, per-layer hipEvent timing.  Host code only; kernels live in k_*.hip.
+#include <new>
+#include <vector>
+
+#include "sicn_internal.h"
+
+using namespace sicn;
+
+static int g_force_generic = 0;
+
+extern "C" int sicn_version(void) { return 1000 * 0 + 1; }
+
+extern "C" const char *sicn_strerror(int code)
+{
+    switch (code) {
+    case SICN_OK: return "ok";
+    case SICN_EINVAL: return "invalid descriptor or argument";
+    case SICN_ENOMEM: return "out of memory";
+    case SICN_ENODEV: return "HIP device/runtime error";
+    case SICN_ENOSPC: return "workspace too small";
+    default: return "unknown error";
+    }
+}
+
+// Shape preconditions of the reference, checked up front instead of CASSERT_DATAFLOW/exit(-1):
+// slidingwindow.h:1259 (IFM_CH % SIMD), mvau.hpp:101-105 (folds), conv_nonsquare_top.cpp:94-95 and
+// :246-259 (output dims), config_nonsquare.h (K=5, S=2, P=2, 8/8/4 bit).
+static int validate_weights_fields(const sicn_layer_desc *d)
+{
+    if (!d) return SICN_EINVAL;
+    if (d->IFM_CH <= 0 || d->OFM_CH <= 0 || d->SIMD <= 0 || d->PE <= 0) return SICN_EINVAL;
+    if (d->SIMD > 16) return SICN_EINVAL;  // SIMD*4 bits must fit a 64-bit word
+    if (d->IFM_CH % d->SIMD || d->OFM_CH % d->PE) return SICN_EINVAL;
+    if ((long long)d->W_TILES != (long long)(d->OFM_CH / d->PE) * (25LL * d->IFM_CH / d->SIMD)) return SICN_EINVAL;
+    if (d->transposed != 0 && d->transposed != 1) return SICN_EINVAL;
+    return SICN_OK;
+}
+
+extern "C" int sicn_validate_desc(const sicn_layer_desc *d)
+{
+    int rc = validate_weights_fields(d);
+    if (rc) return rc;
+    if (d->K != 5 || d->S != 2 || d->P != 2) return SICN_EINVAL;
+    if (d->IN_BIT != 8 || d->OUT_BIT != 8 || d->W_BIT != 4) return SICN_EINVAL;
+    if (d->IFM_ROW <= 0 || d->IFM_COL <= 0) return SICN_EINVAL;
+    if (d->IFM_ROW > (1 << 20) || d->IFM_COL > (1 << 20)) return SICN_EINVAL;
+    if (d->transposed) {
+        if (d->OFM_ROW != 2 * d->IFM_ROW || d->OFM_COL != 2 * d->IFM_COL) return SICN_EINVAL;
+    } else if (d->OFM_ROW != (d->IFM_ROW + 1) / 2 || d->OFM_COL != (d->IFM_COL + 1) / 2)
+        return SICN_EINVAL;
+    return SICN_OK;
+}
+
+namespace sicn {
+KernelKind pick_kernel(const sicn_layer_desc &d)
+{
+    if (g_force_generic) return KK_GENERIC;
+    if (!d.transposed && d.IFM_CH == 3 && d.OFM_CH == 128) return KK_L0_RGB;
+    if (d.transposed && d.IFM_CH == 128 && d.OFM_CH == 3) return KK_L7_RGB;
+    if (mfma_supported(d.IFM_CH, d.OFM_CH)) return d.transposed ? KK_MFMA_DECONV : KK_MFMA_CONV;
+    return KK_GENERIC;
+}
+}  // namespace sicn
+
+extern "C" const char *sicn_kernel_for(const sicn_layer_desc *d)
+{
+    if (sicn_validate_desc(d)) return "invalid";
+    switch (pick_kernel(*d)) {
+    case KK_L0_RGB: return "l0_rgb";
+    case KK_L7_RGB: return "l7_rgb";
+    case KK_MFMA_CONV: return "mfma_conv";
+    case KK_MFMA_DECONV: return "mfma_deconv";
+    default: return "generic";
+    }
+}
+
+extern "C" void sicn_set_force_generic(int on) { g_force_generic = on ? 1 : 0; }
+
+// ---- weights ----------------------------------------------------------------------------------
+static bool upload(const void *host, size_t bytes, int8_t **dev)
+{
+    if (hipMalloc((void **)dev, bytes) != hipSuccess) { *dev = nullptr; return false; }
+    if (hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice) != hipSuccess) return false;
+    return true;
+}
+
+extern "C" void sicn_weights_free(sicn_weights *w)
+{
+    if (!w) return;
+    if (w->d_w_okc) (void)hipFree(w->d_w_okc);
+    if (w->d_bias) (void)hipFree(w->d_bias);
+    if (w->d_w_mfma) (void)hipFree(w->d_w_mfma);
+    if (w->d_w_l0) (void)hipFree(w->d_w_l0);
+    if (w->d_w_l7) (void)hipFree(w->d_w_l7);
+    delete w;
+}
+
+extern "C" int sicn_weights_from_finn_tiles(const sicn_layer_desc *d, const void *m_weights, int word_bytes,
+                                            const int8_t *bias, sicn_weights **out)
+{
+    if (!out) return SICN_EINVAL;
+    *out = nullptr;
+    int rc = validate_weights_fields(d);
+    if (rc || !m_weights || !bias) return SICN_EINVAL;
+    if (word_bytes != 1 && word_bytes != 2 && word_bytes != 4 && word_bytes != 8) return SICN_EINVAL;
+    if (d->SIMD * 4 > word_bytes * 8) return SICN_EINVAL;
+    const int cin = d->IFM_CH, cout = d->OFM_CH, simd = d->SIMD, pe_n = d->PE, tiles = d->W_TILES;
+    const int kk = 25 * cin, sf_n = kk / simd, nf_n = cout / pe_n;
+
+    // FixedPointWeights (weights.hpp:110-150): W[o = nf*PE + pe][k = sf*SIMD + s] = sign-extended
+    // nibble s of m_weights[pe][nf*SF + sf]; k = (ky*5 + kx)*IFM_CH + c (slidingwindow.h:1304-1325,
+    // cross-checked by conv3_nonsquare_tb.cpp:546-571).
+    std::vector<int8_t> w_okc;
+    try {
+        w_okc.resize((size_t)cout * kk);
+    } catch (const std::bad_alloc &) { return SICN_ENOMEM; }
+    const uint8_t *raw = (const uint8_t *)m_weights;
+    for (int pe = 0; pe < pe_n; pe++)
+        for (int nf = 0; nf < nf_n; nf++)
+            for (int sf = 0; sf < sf_n; sf++) {
+                const size_t idx = (size_t)pe * tiles + (size_t)nf * sf_n + sf;
+                uint64_t word = 0;
+                for (int b = 0; b < word_bytes; b++) word |= (uint64_t)raw[idx * word_bytes + b] << (8 * b);
+                for (int s = 0; s < simd; s++) {
+                    int v = (int)((word >> (4 * s)) & 15u);
+                    if (v > 7) v -= 16;
+                    w_okc[(size_t)(nf * pe_n + pe) * kk + sf * simd + s] = (int8_t)v;
+                }
+            }
+
+    sicn_weights *w = new (std::nothrow) sicn_weights();
+    if (!w) return SICN_ENOMEM;
+    *w = sicn_weights{};
+    w->cin = cin;
+    w->cout = cout;
+    w->transposed = d->transposed;
+    bool ok = upload(w_okc.data(), w_okc.size(), &w->d_w_okc);
+    {   // bias, padded to a multiple of 16 bytes so kernels may read it with 16-byte loads
+        std::vector<int8_t> b(((size_t)cout + 15) / 16 * 16 + 16, 0);
+        for (int i = 0; i < cout; i++) b[i] = bias[i];
+        ok = ok && upload(b.data(), b.size(), &w->d_bias);
+    }
+    try {
+        if (ok && mfma_supported(cin, cout)) {
+            std::vector<int8_t> s(mfma_stream_bytes(cin, cout));
+            pack_mfma_stream(w_okc.data(), cin, cout, d->transposed, s.data());
+            w->mfma_steps = mfma_stream_steps(cin);
+            ok = upload(s.data(), s.size(), &w->d_w_mfma);
+        }
+        if (ok && !d->transposed && cin == 3 && cout % 32 == 0) {
+            std::vector<int8_t> s(l0_bytes(cout));
+            pack_l0(w_okc.data(), cout, s.data());
+            ok = upload(s.data(), s.size(), &w->d_w_l0);
+        }
+        if (ok && d->transposed && cin == 128 && cout == 3) {
+            std::vector<int8_t> s(l7_bytes(cin));
+            pack_l7(w_okc.data(), cin, s.data());
+            ok = upload(s.data(), s.size(), &w->d_w_l7);
+        }
+    } catch (const std::bad_alloc &) { ok = false; }
+    if (!ok) {
+        sicn_weights_free(w);
+        return SICN_ENOMEM;
+    }
+    *out = w;
+    return SICN_OK;
+}
+
+// ---- single layers ------------------------------------------------------------------------------
+static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint8_t *in, uint8_t *out,
+                     int n_images, hipStream_t stream, int want_transposed)
+{
+    int rc = sicn_validate_desc(d);
+    if (rc) return rc;
+    if (!w || !in || !out || n_images < 0) return SICN_EINVAL;
+    if (want_transposed >= 0 && d->transposed != want_transposed) return SICN_EINVAL;
+    if (w->cin != d->IFM_CH || w->cout != d->OFM_CH || w->transposed != d->transposed) return SICN_EINVAL;
+    if (n_images == 0) return SICN_OK;
+    if (n_images > 65535) return SICN_EINVAL;
+    const LayerGeom g = geom_of(*d);
+    hipError_t e;
+    switch (pick_kernel(*d)) {
+    case KK_L0_RGB: e = launch_l0(g, *w, in, out, n_images, stream); break;
+    case KK_L7_RGB: e = launch_l7(g, *w, in, out, n_images, stream); break;
+    case KK_MFMA_CONV:
+    case KK_MFMA_DECONV: e = launch_mfma(g, *w, in, out, n_images, stream); break;
+    default: e = launch_generic(g, *w, in, out, n_images, stream); break;
+    }
+    if (e == hipErrorInvalidValue) return SICN_EINVAL;
+    return e == hipSuccess ? SICN_OK : SICN_ENODEV;
+}
+
+extern "C" int sicn_conv2d(const sicn_layer_desc *d, const sicn_weights *w, const uint8_t *in, uint8_t *out,
+                           int n_images, void *hip_stream)
+{
+    return run_layer(d, w, in, out, n_images, (hipStream_t)hip_stream, 0);
+}
+
+extern "C" int sicn_deconv522(const sicn_layer_desc *d, const sicn_weights *w, const uint8_t *in,
+                              uint8_t *out, int n_images, void *hip_stream)
+{
+    return run_layer(d, w, in, out, n_images, (hipStream_t)hip_stream, 1);
+}
+
+// ---- layer chains ---------------------------------------------------------------------------------
+struct sicn_net {
+    std::vector<sicn_layer_desc> descs;
+    std::vector<const sicn_weights *> weights;
+    // profiling
+    bool profile = false;
+    static constexpr int EV_RING = 1024;
+    std::vector<hipEvent_t> ev_begin, ev_end;  // [layer * EV_RING + slot]
+    std::vector<int> ev_count;                 // launches recorded per layer since reset
+};
+
+static size_t out_bytes(const sicn_layer_desc &d) { return (size_t)d.OFM_COL * d.OFM_ROW * d.OFM_CH; }
+static size_t in_bytes(const sicn_layer_desc &d) { return (size_t)d.IFM_COL * d.IFM_ROW * d.IFM_CH; }
+static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+extern "C" int sicn_net_create(const sicn_layer_desc *descs, sicn_weights *const *weights, int n_layers,
+                               sicn_net **out)
+{
+    if (!out) return SICN_EINVAL;
+    *out = nullptr;
+    if (!descs || !weights || n_layers <= 0 || n_layers > 64) return SICN_EINVAL;
+    for (int i = 0; i < n_layers; i++) {
+        int rc = sicn_validate_desc(&descs[i]);
+        if (rc) return rc;
+        const sicn_weights *w = weights[i];
+        if (!w || w->cin != descs[i].IFM_CH || w->cout != descs[i].OFM_CH || w->transposed != descs[i].transposed)
+            return SICN_EINVAL;
+        if (i > 0 && (descs[i].IFM_CH != descs[i - 1].OFM_CH || descs[i].IFM_ROW != descs[i - 1].OFM_ROW ||
+                      descs[i].IFM_COL != descs[i - 1].OFM_COL))
+            return SICN_EINVAL;
+    }
+    sicn_net *net = new (std::nothrow) sicn_net();
+    if (!net) return SICN_ENOMEM;
+    try {
+        net->descs.assign(descs, descs + n_layers);
+        net->weights.assign(weights, weights + n_layers);
+        net->ev_count.assign(n_layers, 0);
+    } catch (const std::bad_alloc &) {
+        delete net;
+        return SICN_ENOMEM;
+    }
+    *out = net;
+    return SICN_OK;
+}
+
+extern "C" void sicn_net_free(sicn_net *net)
+{
+    if (!net) return;
+    for (hipEvent_t e : net->ev_begin) (void)hipEventDestroy(e);
+    for (hipEvent_t e : net->ev_end) (void)hipEventDestroy(e);
+    delete net;
+}
+
+// Two ping-pong buffers, each large enough for the largest intermediate activation.
+static size_t pingpong_slot_bytes(const sicn_net *net, int n_images)
+{
+    size_t mx = 0;
+    for (size_t i = 0; i + 1 < net->descs.size(); i++) mx = mx > out_bytes(net->descs[i]) ? mx : out_bytes(net->descs[i]);
+    return align256(mx * (size_t)n_images);
+}
+
+extern "C" size_t sicn_net_workspace_bytes(const sicn_net *net, int n_images)
+{
+    if (!net || n_images <= 0) return 0;
+    return 2 * pingpong_slot_bytes(net, n_images);
+}
+
+extern "C" int sicn_net_forward(const sicn_net *net_c, int first, int last, const uint8_t *in, uint8_t *out,
+                                int tap_layer, uint8_t *tap_out, int n_images, void *workspace,
+                                size_t workspace_bytes, void *hip_stream)
+{
+    sicn_net *net = const_cast<sicn_net *>(net_c);  // profiling counters only
+    if (!net || !in || !out || n_images < 0) return SICN_EINVAL;
+    const int n_layers = (int)net->descs.size();
+    if (first < 0 || last >= n_layers || first > last) return SICN_EINVAL;
+    if (tap_layer >= 0 && (tap_layer < first || tap_layer > last || !tap_out)) return SICN_EINVAL;
+    if (n_images == 0) return SICN_OK;
+    const size_t slot = pingpong_slot_bytes(net, n_images);
+    if (last > first && (!workspace || workspace_bytes < 2 * slot)) return SICN_ENOSPC;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    uint8_t *pp[2] = {(uint8_t *)workspace, (uint8_t *)workspace + slot};
+    const uint8_t *cur = in;
+    for (int l = first; l <= last; l++) {
+        uint8_t *dst = (l == last) ? out : pp[(l - first) & 1];
+        const bool prof = net->profile && net->ev_count[l] < sicn_net::EV_RING;
+        if (prof && hipEventRecord(net->ev_begin[(size_t)l * sicn_net::EV_RING + net->ev_count[l]], stream) != hipSuccess)
+            return SICN_ENODEV;
+        int rc = run_layer(&net->descs[l], net->weights[l], cur, dst, n_images, stream, -1);
+        if (rc) return rc;
+        if (prof) {
+            if (hipEventRecord(net->ev_end[(size_t)l * sicn_net::EV_RING + net->ev_count[l]], stream) != hipSuccess)
+                return SICN_ENODEV;
+            net->ev_count[l]++;
+        }
+        if (l == tap_layer && tap_out != dst) {
+            if (hipMemcpyAsync(tap_out, dst, out_bytes(net->descs[l]) * (size_t)n_images, hipMemcpyDeviceToDevice,
+                               stream) != hipSuccess)
+                return SICN_ENODEV;
+        }
+        cur = dst;
+    }
+    (void)in_bytes;
+    return SICN_OK;
+}
+
+extern "C" int sicn_eight_layers_net(const sicn_net *net, const uint8_t *in, uint8_t *out, uint8_t *latent,
+                                     int n_images, void *workspace, size_t workspace_bytes, void *hip_stream)
+{
+    if (!net) return SICN_EINVAL;
+    const int n = (int)net->descs.size();
+    const int tap = latent ? 3 : -1;
+    if (latent && n < 4) return SICN_EINVAL;
+    return sicn_net_forward(net, 0, n - 1, in, out, tap, latent, n_images, workspace, workspace_bytes, hip_stream);
+}
+
+extern "C" int sicn_net_profile(sicn_net *net, int enable)
+{
+    if (!net) return SICN_EINVAL;
+    if (enable && net->ev_begin.empty()) {
+        const size_t n = net->descs.size() * (size_t)sicn_net::EV_RING;
+        try {
+            net->ev_begin.reserve(n);
+            net->ev_end.reserve(n);
+        } catch (const std::bad_alloc &) { return SICN_ENOMEM; }
+        for (size_t i = 0; i < n; i++) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess) return SICN_ENODEV;
+            net->ev_begin.push_back(a);
+            if (hipEventCreate(&b) != hipSuccess) return SICN_ENODEV;
+            net->ev_end.push_back(b);
+        }
+    }
+    net->profile = enable != 0;
+    return SICN_OK;
+}
+
+extern "C" int sicn_net_layer_ms(sicn_net *net, int reset, float *ms_sum, int *launches)
+{
+    if (!net || !ms_sum || !launches) return SICN_EINVAL;
+    for (size_t l = 0; l < net->descs.size(); l++) {
+        float sum = 0.f;
+        for (int k = 0; k < net->ev_count[l]; k++) {
+            const size_t i = l * sicn_net::EV_RING + k;
+            if (hipEventSynchronize(net->ev_end[i]) != hipSuccess) return SICN_ENODEV;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, net->ev_begin[i], net->ev_end[i]) != hipSuccess) return SICN_ENODEV;
+            sum += ms;
+        }
+        ms_sum[l] = sum;
+        launches[l] = net->ev_count[l];
+        if (reset) net->ev_count[l] = 0;
+    }
+    return SICN_OK;
+}

@@ -1,0 +1,76 @@
+// Internal declarations shared by the libsicn.so translation units (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/sicn.h"
+
+namespace sicn {
+
+// Geometry of the implicit-GEMM kernels (k_mfma.hip).  One workgroup owns an "M tile" of
+// TILE_Y x TILE_X positions of the M grid (conv: output pixels; deconv: input pixels) and all
+// output channels.  LDS holds SUB sub-patches of (TILE_Y+2) x (TILE_X+2) positions x 32 bytes.
+constexpr int TILE_Y = 8;
+constexpr int TILE_X = 32;
+constexpr int PATCH_Y = TILE_Y + 2;
+constexpr int PATCH_X = TILE_X + 2;
+constexpr int PATCH_PIX = PATCH_Y * PATCH_X;  // 340
+constexpr int KSTEP = 32;                      // bytes of K per MFMA (v_mfma_i32_32x32x32_i8)
+
+enum KernelKind : int { KK_GENERIC = 0, KK_MFMA_CONV, KK_MFMA_DECONV, KK_L0_RGB, KK_L7_RGB };
+
+struct LayerGeom {
+    int IW, IH, CIN, OW, OH, COUT, transposed;
+};
+
+inline LayerGeom geom_of(const sicn_layer_desc &d)
+{
+    return LayerGeom{d.IFM_ROW, d.IFM_COL, d.IFM_CH, d.OFM_ROW, d.OFM_COL, d.OFM_CH, d.transposed};
+}
+
+}  // namespace sicn
+
+// One layer's device-resident parameters, in every layout a kernel family wants.
+struct sicn_weights {
+    int cin, cout, transposed;
+    int8_t *d_w_okc;      // [cout][25*cin] int8, k = (ky*5+kx)*cin + c        (generic kernel)
+    int8_t *d_bias;       // [cout] int8
+    // implicit-GEMM tile stream (k_mfma.hip), or nullptr when the shape is not served by it:
+    // n_steps tiles of [cout rows][32 B] in consumption order, rows permuted (sigma) and the two
+    // 16-byte halves of a row swapped where the LDS swizzle wants it.
+    int8_t *d_w_mfma;
+    int mfma_steps;
+    int8_t *d_bias_sigma;  // [cout] bias in sigma order == natural order (kept for clarity)
+    // layer-0 (RGB -> cout) and layer-7 (cin -> RGB) layouts, or nullptr
+    int8_t *d_w_l0;
+    int8_t *d_w_l7;
+};
+
+namespace sicn {
+
+KernelKind pick_kernel(const sicn_layer_desc &d);
+
+// Launchers: enqueue on `stream`, return hipError_t of the launch.
+hipError_t launch_generic(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
+                          int n_images, hipStream_t stream);
+hipError_t launch_mfma(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
+                       int n_images, hipStream_t stream);
+hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
+                     int n_images, hipStream_t stream);
+hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
+                     int n_images, hipStream_t stream);
+
+// Host-side weight packers (pure CPU, unit-testable without a GPU).
+// w_okc: [cout][25*cin].  Returns bytes written into `dst` (size from *_bytes()).
+size_t mfma_stream_bytes(int cin, int cout);
+int mfma_stream_steps(int cin);
+void pack_mfma_stream(const int8_t *w_okc, int cin, int cout, int transposed, int8_t *dst);
+bool mfma_supported(int cin, int cout);
+
+size_t l0_bytes(int cout);
+void pack_l0(const int8_t *w_okc, int cout, int8_t *dst);
+size_t l7_bytes(int cin);
+void pack_l7(const int8_t *w_okc, int cin, int8_t *dst);
+
+}  // namespace sicn

@@ -1,0 +1,69 @@
+"""CPU-only checks of the C-ABI shared library: it loads, exports every symbol include/sicn.h
+declares, and its pure-host entry points behave (no compute calls — those need the GPU)."""
+import ctypes
+import re
+from dataclasses import replace
+from pathlib import Path
+
+import pytest
+
+from simple_image_compression_network_amd import _lib
+from simple_image_compression_network_amd.config import REFERENCE_DESCS, eight_layer_descs
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _declared_symbols():
+    text = (ROOT / "include" / "sicn.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sicn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(str(_lib.LIB_PATH))
+    syms = _declared_symbols()
+    assert len(syms) >= 16
+    for s in syms:
+        assert hasattr(L, s), f"libsicn.so does not export {s}"
+    assert set(syms) == set(_lib.ABI), "python binding table and sicn.h disagree"
+
+
+def test_version_and_strerror():
+    L = _lib.lib()
+    assert L.sicn_version() >= 1
+    assert L.sicn_strerror(0) == b"ok"
+    assert b"invalid" in L.sicn_strerror(-22)
+
+
+def test_validate_desc_matches_python_validate():
+    L = _lib.lib()
+    for d in REFERENCE_DESCS + eight_layer_descs(1920, 1080) + eight_layer_descs(37, 21):
+        assert L.sicn_validate_desc(ctypes.byref(d.to_c())) == 0
+    d = REFERENCE_DESCS[1]
+    bad = [replace(d, K=3), replace(d, S=1), replace(d, SIMD=7), replace(d, PE=5), replace(d, W_TILES=1),
+           replace(d, OFM_ROW=d.OFM_ROW + 1), replace(d, IN_BIT=4), replace(d, W_BIT=8), replace(d, IFM_ROW=0),
+           replace(d, transposed=1), replace(d, transposed=2)]
+    for b in bad:
+        assert L.sicn_validate_desc(ctypes.byref(b.to_c())) == -22
+        with pytest.raises(ValueError):
+            b.validate()
+    assert L.sicn_validate_desc(None) == -22
+
+
+def test_kernel_selection_for_reference_net():
+    L = _lib.lib()
+    kinds = [L.sicn_kernel_for(ctypes.byref(d.to_c())).decode() for d in REFERENCE_DESCS]
+    assert kinds == ["l0_rgb", "mfma_conv", "mfma_conv", "mfma_conv", "mfma_deconv", "mfma_deconv",
+                     "mfma_deconv", "l7_rgb"]
+    odd = replace(REFERENCE_DESCS[1], IFM_CH=6, OFM_CH=4, SIMD=3, PE=2, W_TILES=(4 // 2) * (150 // 3))
+    assert L.sicn_kernel_for(ctypes.byref(odd.to_c())) == b"generic"
+
+
+def test_null_arguments_are_rejected_without_touching_the_gpu():
+    L = _lib.lib()
+    d = REFERENCE_DESCS[0].to_c()
+    out = ctypes.c_void_p()
+    assert L.sicn_weights_from_finn_tiles(ctypes.byref(d), None, 8, None, ctypes.byref(out)) == -22
+    assert L.sicn_conv2d(ctypes.byref(d), None, None, None, 1, None) == -22
+    assert L.sicn_net_create(None, None, 0, ctypes.byref(out)) == -22
+    assert L.sicn_net_workspace_bytes(None, 1) == 0
