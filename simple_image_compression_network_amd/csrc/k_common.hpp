@@ -10,7 +10,12 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
 
-constexpr int SUB_BYTES = PATCH_PIX * KSTEP;  // 10880 bytes per sub-patch
+// One sub-patch = (TILE_Y+2) x (TILE_X+2) positions x 32 channel bytes = 10880 B, filled by 1-KiB
+// LDS-DMA pieces (one wave-wide 16-byte load each) and padded to 12 pieces so that every wave of a
+// 4-wave workgroup issues the same number of pieces (3) per sub-patch.
+constexpr int SUB_BYTES = PATCH_PIX * KSTEP;  // 10880
+constexpr int SUB_PIECES = 12;
+constexpr int SUB_ALLOC = SUB_PIECES * 1024;  // 12288
 constexpr int RING = 4;                       // weight-tile ring slots
 constexpr int PF = 3;                         // weight tiles in flight ahead of the consumer
 constexpr uint32_t OOB = 0x80000000u;         // beyond any image: the buffer range check returns 0
@@ -30,14 +35,6 @@ __device__ __forceinline__ void block_barrier()
     asm volatile("" ::: "memory");
 }
 
-template <int NSUB>
-struct PatchGeom {
-    static constexpr int BYTES = NSUB * SUB_BYTES;
-    static constexpr int PIECES = (BYTES + 1023) / 1024;  // 1 KiB = one wave-wide 16-byte LDS-DMA
-    static constexpr int ALLOC = PIECES * 1024;
-    static constexpr int ROUNDS = (PIECES + 3) / 4;
-};
-
 // relu7((v) mod 256) for four accumulators, packed little-endian into one dword.
 __device__ __forceinline__ uint32_t pack4_relu7(int a, int b, int c, int d)
 {
@@ -46,5 +43,56 @@ __device__ __forceinline__ uint32_t pack4_relu7(int a, int b, int c, int d)
     return (uint32_t)sa | ((uint32_t)sb << 8) | ((uint32_t)sc << 16) | ((uint32_t)sd << 24);
 }
 
+// Tensor layouts.  NHWC  : [H][W][C]           (the ABI layout = the reference's stream bytes)
+//                  GROUP : [C/32][H][W][32]     (internal, between two layers of a chain: every
+//                          32-channel group is its own plane, so a kernel that walks K group by
+//                          group touches each 128-byte line once, and a lane-per-pixel epilogue
+//                          stores 1 KiB contiguous per wave instruction)
+// Byte offset of (pixel index pix, channel group g) and the stride between groups of one pixel:
+__device__ __forceinline__ uint32_t pix_group_offset(bool grouped, uint32_t pix, uint32_t g, uint32_t C,
+                                                     uint32_t plane_pixels)
+{
+    return grouped ? (g * plane_pixels + pix) * 32u : pix * C + g * 32u;
+}
+
+// Source offset (bytes from the image base) of this lane's 16 bytes of LDS-DMA piece `k` of a
+// sub-patch: position p = k*32 + lane/2 of the (TILE_Y+2) x (TILE_X+2) window whose origin is
+// (Yb, Xb) in "patch coordinates"; patch coordinate (ty,tx) maps to input pixel
+// (sy*(Yb+ty)+ay, sx*(Xb+tx)+ax).  The LDS image keeps logical half h of position p at physical
+// half h ^ ((p>>3)&1) (bank-conflict-free ds_read_b128).
+__device__ __forceinline__ uint32_t piece_src_offset(int k, int lane, int Yb, int Xb, int s, int ay, int ax,
+                                                     int IW, int IH, bool grouped, uint32_t g, uint32_t C)
+{
+    const int p = k * 32 + (lane >> 1);
+    const int ty = p / PATCH_X, tx = p - ty * PATCH_X;
+    const int hlog = (lane & 1) ^ ((p >> 3) & 1);
+    const int iy = s * (Yb + ty) + ay, ix = s * (Xb + tx) + ax;
+    const bool ok = p < PATCH_PIX && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
+    return ok ? pix_group_offset(grouped, (uint32_t)(iy * IW + ix), g, C, (uint32_t)(IW * IH)) + hlog * 16 : OOB;
+}
+
+// one LDS-DMA piece (1 KiB) of sub-patch `sub`
+__device__ __forceinline__ void load_piece(uint8_t *patch, const uint8_t *in_img, int in_img_bytes, int sub,
+                                           int k, uint32_t off)
+{
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)in_img, 0, in_img_bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(patch + sub * SUB_ALLOC + k * 1024), 16, off, 0, 0, 0);
+}
+
+// ---- conv tap order: by parity plane (a,b) = (ky&1, kx&1), so that a plane's LDS buffer is
+// ---- free for the next channel group as soon as its taps are done (k_mfma.hip) -------------
+struct Tap { int ky, kx; };
+__host__ __device__ constexpr Tap conv_tap(int t)
+{
+    int n = 0;
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 2; b++)
+            for (int ky = a; ky < 5; ky += 2)
+                for (int kx = b; kx < 5; kx += 2) {
+                    if (n == t) return Tap{ky, kx};
+                    n++;
+                }
+    return Tap{-1, -1};
+}
 
 }  // namespace sicn

@@ -16,7 +16,9 @@
 //   conv, stride 2 : the input is split into 4 parity planes P[a][b][i][j] = in[2i+a][2j+b]; tap
 //                    (ky,kx) of output (y,x) reads plane (ky&1,kx&1) at (y+(ky>>1)-1, x+(kx>>1)-1),
 //                    i.e. a unit-stride access.  K is walked as 32-channel groups (outer) x 25
-//                    taps (inner); the patch of one channel group (4 planes) sits in LDS.
+//                    taps (inner, ordered plane by plane); the 4 planes of one channel group sit
+//                    in LDS and each plane is re-filled with the NEXT channel group as soon as its
+//                    taps are done, under the MFMAs of the other planes.
 //   deconv         : 4 output phases (py,px); phase (py,px) of input position (y,x) is output
 //                    (2y+py,2x+px) and only uses taps ky=py, kx=px (mod 2), reading input
 //                    (y+((ky+py)>>1)-1, x+((kx+px)>>1)-1).  The inserted zeros are never touched
@@ -28,6 +30,9 @@
 // position), so a lane's 16 accumulators of one tile are 16 CONSECUTIVE output channels of ONE
 // pixel (weight rows are stored permuted: LDS row (a + 4h + 8d) holds channel 16h + 4d + a), and
 // the epilogue stores 16 bytes per lane straight from registers.
+//
+// Tensor layouts: NHWC (ABI) or GROUP = [C/32][H][W][32] (between two layers of a chain), chosen
+// per side by run-time flags; see k_common.hpp.
 #include "k_common.hpp"
 
 namespace sicn {
@@ -35,19 +40,6 @@ namespace sicn {
 // ---- device helpers -------------------------------------------------------------------------
 // (plain function templates on purpose: lambdas inside a __global__ template make hipcc's
 //  host-side instantiation of the kernel fail with a silent substitution failure, ROCm 7.2)
-template <int ROUNDS, int PIECES>
-__device__ __forceinline__ void load_patch(uint8_t *patch, const uint8_t *in_img, int in_img_bytes,
-                                           const uint32_t (&poff)[ROUNDS], int q, int w)
-{
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)in_img, 0, in_img_bytes, 0x00020000);
-#pragma unroll
-    for (int r = 0; r < ROUNDS; r++) {
-        const int piece = r * 4 + w;
-        if (piece < PIECES)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(patch + piece * 1024), 16,
-                                                     poff[r] + (uint32_t)(q * 32), 0, 0, 0);
-    }
-}
 
 template <int TB>
 __device__ __forceinline__ void load_wtile(uint8_t *ring, const int8_t *wstream, int step, int lane, int w)
@@ -98,26 +90,11 @@ __device__ __forceinline__ void mma_step(v16i (&acc)[2][NTJ], const uint8_t *sub
             acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[j], pf[i], acc[i][j], 0, 0, 0);
 }
 
-// one K step: top up the weight ring, consume tile `step`, publish tile step+1
-template <int NTJ, int STEPS>
-__device__ __forceinline__ void k_step(v16i (&acc)[2][NTJ], const uint8_t *patch, uint8_t *ring,
-                                       const int8_t *wstream, const uint32_t (&wrow)[NTJ], int p_lane, int kh,
-                                       int lane, int w, int step, int sub, int oy, int ox)
-{
-    constexpr int TB = NTJ * 32 * KSTEP, WR = (TB / 1024 + 3) / 4;
-    if (step + PF < STEPS) load_wtile<TB>(ring, wstream, step + PF, lane, w);
-    mma_step<NTJ>(acc, patch + sub * SUB_BYTES, ring + (step % RING) * TB, wrow, p_lane, kh, oy, ox);
-    if (step + PF < STEPS)
-        wait_vmcnt<(PF - 1) * WR>();
-    else
-        wait_vmcnt<0>();
-    block_barrier();
-}
-
 // bias is already in the accumulator: truncate mod 256, relu7, 16 consecutive channels per lane
 template <int NTJ>
-__device__ __forceinline__ void store_tiles(const v16i (&acc)[2][NTJ], uint8_t *out_img, int OW, int MW, int MH,
-                                            int Y0, int X0, int w, int m, int kh, bool deconv, int py, int px)
+__device__ __forceinline__ void store_tiles(const v16i (&acc)[2][NTJ], uint8_t *out_img, int OW, int OH, int MW,
+                                            int MH, int Y0, int X0, int w, int m, int kh, bool deconv, int py,
+                                            int px, bool out_grouped)
 {
     constexpr int COUT = NTJ * 32;
 #pragma unroll
@@ -125,7 +102,7 @@ __device__ __forceinline__ void store_tiles(const v16i (&acc)[2][NTJ], uint8_t *
         const int gy = Y0 + 2 * w + i, gx = X0 + m;
         if (gy < MH && gx < MW) {
             const int oy_ = deconv ? 2 * gy + py : gy, ox_ = deconv ? 2 * gx + px : gx;
-            uint8_t *dst = out_img + ((size_t)oy_ * OW + ox_) * COUT + 16 * kh;
+            const size_t pix = (size_t)oy_ * OW + ox_;
 #pragma unroll
             for (int j = 0; j < NTJ; j++) {
                 const v16i a = acc[i][j];
@@ -134,26 +111,86 @@ __device__ __forceinline__ void store_tiles(const v16i (&acc)[2][NTJ], uint8_t *
                 v.y = pack4_relu7(a[4], a[5], a[6], a[7]);
                 v.z = pack4_relu7(a[8], a[9], a[10], a[11]);
                 v.w = pack4_relu7(a[12], a[13], a[14], a[15]);
-                *(uint4 *)(dst + j * 32) = v;
+                uint8_t *dst = out_grouped ? out_img + ((size_t)j * OW * OH + pix) * 32 + 16 * kh
+                                           : out_img + pix * COUT + j * 32 + 16 * kh;
+                *(uint4 *)dst = v;
             }
         }
     }
 }
 
+// Everything one K step needs, so that the 25 conv steps can be expanded by template recursion
+// (their vmcnt immediates and plane-refresh slots are compile-time functions of the tap index).
+template <int NTJ>
+struct StepCtx {
+    v16i (&acc)[2][NTJ];
+    uint8_t *patch;
+    uint8_t *ring;
+    const int8_t *wstream;
+    const uint32_t (&wrow)[NTJ];
+    const uint8_t *in_img;
+    int in_img_bytes;
+    int p_lane, kh, lane, w;
+};
+
+// conv: which plane does step t (0..24, plane order) refresh, if any?  slot i = pieces 4i+w
+__host__ __device__ constexpr int refresh_plane(int t)
+{
+    return (t >= 0 && t < 3) ? 3 : (t >= 9 && t < 12) ? 0 : (t >= 15 && t < 18) ? 1 : (t >= 21 && t < 24) ? 2 : -1;
+}
+__host__ __device__ constexpr int refresh_slot(int t) { return t < 3 ? t : t < 12 ? t - 9 : t < 18 ? t - 15 : t - 21; }
+__host__ __device__ constexpr int has_refresh(int t) { return refresh_plane((t + 25) % 25) >= 0 ? 1 : 0; }
+
+template <int NTJ, int T>
+__device__ __forceinline__ void conv_steps(const StepCtx<NTJ> &c, const uint32_t (&poff)[4][3], int q, uint32_t qstride)
+{
+    constexpr int TB = NTJ * 32 * KSTEP, WR = (TB / 1024 + 3) / 4;
+    constexpr Tap tap = conv_tap(T);
+    constexpr int plane = (tap.ky & 1) * 2 + (tap.kx & 1);
+    const int step = q * 25 + T;
+    // (1) plane refresh: plane 3 takes THIS group's data (it was last used by the previous group's
+    //     final taps), planes 0..2 take the NEXT group's as soon as their own taps are done.
+    //     A refresh with group == NQ reads past the last group: never consumed.
+    constexpr int rp = refresh_plane(T);
+    if constexpr (rp >= 0) {
+        constexpr int slot = refresh_slot(T);
+        const int qq = (rp == 3) ? q : q + 1;
+        load_piece(c.patch, c.in_img, c.in_img_bytes, rp, slot * 4 + c.w, poff[rp][slot] + (uint32_t)qq * qstride);
+    }
+    // (2) weight ring top-up (the stream is padded with PF dummy tiles), (3) MFMAs
+    load_wtile<TB>(c.ring, c.wstream, step + PF, c.lane, c.w);
+    mma_step<NTJ>(c.acc, c.patch + plane * SUB_ALLOC, c.ring + (step % RING) * TB, c.wrow, c.p_lane, c.kh,
+                  tap.ky >> 1, tap.kx >> 1);
+    // (4) publish weight tile step+1 (issued 2 steps ago, before that step's B pieces) and, with
+    //     it, every patch piece issued before it
+    wait_vmcnt<(PF - 1) * WR + has_refresh(T - 1) + has_refresh(T)>();
+    block_barrier();
+    if constexpr (T + 1 < 25) conv_steps<NTJ, T + 1>(c, poff, q, qstride);
+}
+
+template <int NTJ>
+__device__ __forceinline__ void deconv_step(const StepCtx<NTJ> &c, int step, int sub, int oy, int ox)
+{
+    constexpr int TB = NTJ * 32 * KSTEP, WR = (TB / 1024 + 3) / 4;
+    load_wtile<TB>(c.ring, c.wstream, step + PF, c.lane, c.w);
+    mma_step<NTJ>(c.acc, c.patch + sub * SUB_ALLOC, c.ring + (step % RING) * TB, c.wrow, c.p_lane, c.kh, oy, ox);
+    wait_vmcnt<(PF - 1) * WR>();
+    block_barrier();
+}
+
 template <int NQ, int NTJ, bool DECONV, int MINW>
 __global__ __launch_bounds__(256, MINW) void k_mfma_t(
     const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int8_t *__restrict__ wstream,
-    const int8_t *__restrict__ bias, int IW, int IH, int OW, int OH, int MW, int MH, int tiles_x)
+    const int8_t *__restrict__ bias, int IW, int IH, int OW, int OH, int MW, int MH, int tiles_x, int in_grouped,
+    int out_grouped)
 {
     constexpr int CIN = NQ * 32, COUT = NTJ * 32;
     constexpr int NSUB = DECONV ? NQ : 4;
-    using PG = PatchGeom<NSUB>;
     constexpr int TB = COUT * KSTEP;  // weight tile bytes
-    constexpr int STEPS = 25 * NQ;
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *patch = smem;
-    uint8_t *ring = smem + PG::ALLOC;
+    uint8_t *ring = smem + NSUB * SUB_ALLOC;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -162,47 +199,32 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_t(
     const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
     const int Y0 = tile_y * TILE_Y, X0 = tile_x * TILE_X;
 
-    // ---- per-lane source offsets of the patch pieces (bytes from the image base) --------------
     const int in_img_bytes = IH * IW * CIN;
     const uint8_t *in_img = in + (size_t)img * in_img_bytes;
     uint8_t *out_img = out + (size_t)img * OH * OW * COUT;
-    uint32_t poff[PG::ROUNDS];
-#pragma unroll
-    for (int r = 0; r < PG::ROUNDS; r++) {
-        const int piece = r * 4 + w;
-        const int gp = piece * 32 + (lane >> 1);
-        const int sub = gp / PATCH_PIX, p = gp - sub * PATCH_PIX;
-        const int ty = p / PATCH_X, tx = p - ty * PATCH_X;
-        const int hlog = (lane & 1) ^ ((p >> 3) & 1);
-        int iy, ix;
-        if (DECONV) {
-            iy = Y0 - 1 + ty;
-            ix = X0 - 1 + tx;
-        } else {
-            iy = 2 * (Y0 - 1 + ty) + (sub >> 1);
-            ix = 2 * (X0 - 1 + tx) + (sub & 1);
-        }
-        const bool ok = sub < NSUB && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
-        poff[r] = ok ? (uint32_t)((iy * IW + ix) * CIN + (DECONV ? sub * 32 : 0) + hlog * 16) : OOB;
-    }
 
-    // ---- per-lane LDS read offsets -----------------------------------------------------------
     // weight rows: LDS row = j*32 + m, logical K half kh at physical half kh ^ ((row>>3)&1)
     uint32_t wrow[NTJ];
 #pragma unroll
     for (int j = 0; j < NTJ; j++) wrow[j] = (uint32_t)((j * 32 + m) * 32 + ((kh ^ ((m >> 3) & 1)) << 4));
-    const int p_lane = (2 * w) * PATCH_X + m;  // + (i + oy) * PATCH_X + ox per tile / tap
 
     v16i acc[2][NTJ];
+    const StepCtx<NTJ> ctx{acc, patch, ring, wstream, wrow, in_img, in_img_bytes, (2 * w) * PATCH_X + m, kh, lane, w};
 
-    // ---- prologue ----------------------------------------------------------------------------
-    load_patch<PG::ROUNDS, PG::PIECES>(patch, in_img, in_img_bytes, poff, 0, w);
+    if constexpr (DECONV) {
+        // ---- prologue: the whole patch (NQ channel groups) + PF weight tiles --------------------
 #pragma unroll
-    for (int s = 0; s < PF; s++) load_wtile<TB>(ring, wstream, s, lane, w);
-    wait_vmcnt<0>();
-    block_barrier();
+        for (int sub = 0; sub < NQ; sub++)
+#pragma unroll
+            for (int slot = 0; slot < 3; slot++)
+                load_piece(patch, in_img, in_img_bytes, sub, slot * 4 + w,
+                           piece_src_offset(slot * 4 + w, lane, Y0 - 1, X0 - 1, 1, 0, 0, IW, IH, in_grouped != 0,
+                                            (uint32_t)sub, CIN));
+#pragma unroll
+        for (int s = 0; s < PF; s++) load_wtile<TB>(ring, wstream, s, lane, w);
+        wait_vmcnt<0>();
+        block_barrier();
 
-    if (DECONV) {
         int step = 0;
 #pragma unroll
         for (int ph = 0; ph < 4; ph++) {
@@ -213,41 +235,47 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_t(
             for (int t = 0; t < ntap; t++) {
                 const int iy = t / nkx, ix = t - iy * nkx;
 #pragma unroll
-                for (int q = 0; q < NQ; q++)
-                    k_step<NTJ, STEPS>(acc, patch, ring, wstream, wrow, p_lane, kh, lane, w, step + q, q, iy + py,
-                                       ix + px);
+                for (int q = 0; q < NQ; q++) deconv_step<NTJ>(ctx, step + q, q, iy + py, ix + px);
                 step += NQ;
             }
-            store_tiles<NTJ>(acc, out_img, OW, MW, MH, Y0, X0, w, m, kh, true, py, px);
+            if (ph == 3) wait_vmcnt<0>();  // the padded tail of the weight prefetch must land before exit
+            store_tiles<NTJ>(acc, out_img, OW, OH, MW, MH, Y0, X0, w, m, kh, true, py, px, out_grouped != 0);
         }
     } else {
+        // ---- per-lane source offsets of the 4 planes x 3 refresh slots (channel group 0) --------
+        uint32_t poff[4][3];
+#pragma unroll
+        for (int pl = 0; pl < 4; pl++)
+#pragma unroll
+            for (int slot = 0; slot < 3; slot++)
+                poff[pl][slot] = piece_src_offset(slot * 4 + w, lane, Y0 - 1, X0 - 1, 2, pl >> 1, pl & 1, IW, IH,
+                                                  in_grouped != 0, 0u, CIN);
+        const uint32_t qstride = in_grouped ? (uint32_t)(IW * IH * 32) : 32u;
+        // ---- prologue: planes 0..2 of group 0 (plane 3 arrives in steps 0..2) + PF weight tiles --
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+            for (int slot = 0; slot < 3; slot++)
+                load_piece(patch, in_img, in_img_bytes, pl, slot * 4 + w, poff[pl][slot]);
+#pragma unroll
+        for (int s = 0; s < PF; s++) load_wtile<TB>(ring, wstream, s, lane, w);
+        wait_vmcnt<0>();
+        block_barrier();
+
         init_acc<NTJ>(acc, bias, kh);
 #pragma unroll 1
-        for (int q = 0; q < NQ; q++) {
-            if (q > 0) {
-                // every wave is past the barrier of the last step of group q-1: the patch is free
-                load_patch<PG::ROUNDS, PG::PIECES>(patch, in_img, in_img_bytes, poff, q, w);
-                wait_vmcnt<0>();
-                block_barrier();
-            }
-#pragma unroll 1
-            for (int ky = 0; ky < 5; ky++)
-#pragma unroll
-                for (int kx = 0; kx < 5; kx++)
-                    k_step<NTJ, STEPS>(acc, patch, ring, wstream, wrow, p_lane, kh, lane, w, q * 25 + ky * 5 + kx,
-                                       (ky & 1) * 2 + (kx & 1), ky >> 1, kx >> 1);
-        }
-        store_tiles<NTJ>(acc, out_img, OW, MW, MH, Y0, X0, w, m, kh, false, 0, 0);
+        for (int q = 0; q < NQ; q++) conv_steps<NTJ, 0>(ctx, poff, q, qstride);
+        wait_vmcnt<0>();
+        store_tiles<NTJ>(acc, out_img, OW, OH, MW, MH, Y0, X0, w, m, kh, false, 0, 0, out_grouped != 0);
     }
 }
 
-
 // Explicit instantiations: the host stubs of a __global__ template that is only named inside
 // another template are not emitted by hipcc (ROCm 7.2) otherwise.
-#define SICN_INST(NQ, NTJ, D)                                                                             \
-    template __global__ void k_mfma_t<NQ, NTJ, D, (NTJ <= 4 ? 2 : 1)>(const uint8_t *__restrict__, uint8_t *__restrict__,       \
-                                                const int8_t *__restrict__, const int8_t *__restrict__,   \
-                                                int, int, int, int, int, int, int);
+#define SICN_INST(NQ, NTJ, D)                                                                               \
+    template __global__ void k_mfma_t<NQ, NTJ, D, (NTJ <= 4 ? 2 : 1)>(                                      \
+        const uint8_t *__restrict__, uint8_t *__restrict__, const int8_t *__restrict__,                     \
+        const int8_t *__restrict__, int, int, int, int, int, int, int, int, int);
 SICN_INST(4, 4, true)
 SICN_INST(6, 4, true)
 SICN_INST(4, 6, true)
@@ -258,18 +286,19 @@ SICN_INST(4, 6, false)
 
 template <int NQ, int NTJ, bool DECONV>
 static hipError_t launch_one(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                             int n_images, hipStream_t stream)
+                             int n_images, hipStream_t stream, int in_grouped, int out_grouped)
 {
     constexpr int NSUB = DECONV ? NQ : 4;
+    constexpr int MINW = (NTJ <= 4 ? 2 : 1);
     const int MW = DECONV ? g.IW : g.OW, MH = DECONV ? g.IH : g.OH;
     const int tiles_x = (MW + TILE_X - 1) / TILE_X, tiles_y = (MH + TILE_Y - 1) / TILE_Y;
-    const size_t lds = PatchGeom<NSUB>::ALLOC + (size_t)RING * NTJ * 32 * KSTEP;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mfma_t<NQ, NTJ, DECONV, (NTJ <= 4 ? 2 : 1)>),
+    const size_t lds = (size_t)NSUB * SUB_ALLOC + (size_t)RING * NTJ * 32 * KSTEP;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mfma_t<NQ, NTJ, DECONV, MINW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)(tiles_x * tiles_y), 1, (unsigned)n_images);
-    hipLaunchKernelGGL((k_mfma_t<NQ, NTJ, DECONV, (NTJ <= 4 ? 2 : 1)>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma, w.d_bias,
-                       g.IW, g.IH, g.OW, g.OH, MW, MH, tiles_x);
+    hipLaunchKernelGGL((k_mfma_t<NQ, NTJ, DECONV, MINW>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma,
+                       w.d_bias, g.IW, g.IH, g.OW, g.OH, MW, MH, tiles_x, in_grouped, out_grouped);
     return hipGetLastError();
 }
 
@@ -279,24 +308,25 @@ bool mfma_supported(int cin, int cout)
 }
 
 hipError_t launch_mfma(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                       int n_images, hipStream_t stream)
+                       int n_images, hipStream_t stream, int in_grouped, int out_grouped)
 {
     if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB) return hipErrorInvalidValue;
     if (g.transposed) {
-        if (g.CIN == 128 && g.COUT == 128) return launch_one<4, 4, true>(g, w, in, out, n_images, stream);
-        if (g.CIN == 192 && g.COUT == 128) return launch_one<6, 4, true>(g, w, in, out, n_images, stream);
-        if (g.CIN == 128 && g.COUT == 192) return launch_one<4, 6, true>(g, w, in, out, n_images, stream);
+        if (g.CIN == 128 && g.COUT == 128) return launch_one<4, 4, true>(g, w, in, out, n_images, stream, in_grouped, out_grouped);
+        if (g.CIN == 192 && g.COUT == 128) return launch_one<6, 4, true>(g, w, in, out, n_images, stream, in_grouped, out_grouped);
+        if (g.CIN == 128 && g.COUT == 192) return launch_one<4, 6, true>(g, w, in, out, n_images, stream, in_grouped, out_grouped);
     } else {
-        if (g.CIN == 128 && g.COUT == 128) return launch_one<4, 4, false>(g, w, in, out, n_images, stream);
-        if (g.CIN == 192 && g.COUT == 128) return launch_one<6, 4, false>(g, w, in, out, n_images, stream);
-        if (g.CIN == 128 && g.COUT == 192) return launch_one<4, 6, false>(g, w, in, out, n_images, stream);
+        if (g.CIN == 128 && g.COUT == 128) return launch_one<4, 4, false>(g, w, in, out, n_images, stream, in_grouped, out_grouped);
+        if (g.CIN == 192 && g.COUT == 128) return launch_one<6, 4, false>(g, w, in, out, n_images, stream, in_grouped, out_grouped);
+        if (g.CIN == 128 && g.COUT == 192) return launch_one<4, 6, false>(g, w, in, out, n_images, stream, in_grouped, out_grouped);
     }
     return hipErrorInvalidValue;
 }
 
 // ---- host-side weight packing --------------------------------------------------------------
+// The stream is padded with PF zero tiles: the kernels prefetch PF tiles past the last step.
 int mfma_stream_steps(int cin) { return 25 * (cin / 32); }
-size_t mfma_stream_bytes(int cin, int cout) { return (size_t)mfma_stream_steps(cin) * cout * KSTEP; }
+size_t mfma_stream_bytes(int cin, int cout) { return (size_t)(mfma_stream_steps(cin) + PF) * cout * KSTEP; }
 
 static void pack_tile(const int8_t *w_okc, int cin, int cout, int tap, int q, int8_t *tile)
 {
@@ -318,7 +348,10 @@ void pack_mfma_stream(const int8_t *w_okc, int cin, int cout, int transposed, in
     size_t step = 0;
     if (!transposed) {
         for (int q = 0; q < nq; q++)
-            for (int tap = 0; tap < 25; tap++) pack_tile(w_okc, cin, cout, tap, q, dst + (step++) * tb);
+            for (int t = 0; t < 25; t++) {
+                const Tap tap = conv_tap(t);
+                pack_tile(w_okc, cin, cout, tap.ky * 5 + tap.kx, q, dst + (step++) * tb);
+            }
     } else {
         for (int ph = 0; ph < 4; ph++) {
             const int py = ph >> 1, px = ph & 1;
@@ -329,6 +362,7 @@ void pack_mfma_stream(const int8_t *w_okc, int cin, int cout, int transposed, in
                 }
         }
     }
+    for (size_t i = step * tb; i < (step + PF) * tb; i++) dst[i] = 0;
 }
 
 }  // namespace sicn

@@ -26,7 +26,7 @@ template <int NTJ>
 __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                const int8_t *__restrict__ w_l0,
                                                const int8_t *__restrict__ bias, int IW, int IH, int OW,
-                                               int OH, int tiles_y, int y_chunks)
+                                               int OH, int tiles_y, int y_chunks, int out_grouped)
 {
     constexpr int COUT = NTJ * 32;
     constexpr int TB = COUT * KSTEP;
@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, u
         for (int i = 0; i < 2; i++) {
             const int gy = Y0 + 2 * w + i, gx = X0 + m;
             if (gy < OH && gx < OW) {
-                uint8_t *dst = out + (((size_t)img * OH + gy) * OW + gx) * COUT + 16 * kh;
+                uint8_t *out_img = out + (size_t)img * OH * OW * COUT;
+                const size_t pix = (size_t)gy * OW + gx;
 #pragma unroll
                 for (int j = 0; j < NTJ; j++) {
                     const v16i a = acc[i][j];
@@ -112,7 +113,9 @@ __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, u
                     v.y = pack4_relu7(a[4], a[5], a[6], a[7]);
                     v.z = pack4_relu7(a[8], a[9], a[10], a[11]);
                     v.w = pack4_relu7(a[12], a[13], a[14], a[15]);
-                    *(uint4 *)(dst + j * 32) = v;
+                    uint8_t *dst = out_grouped ? out_img + ((size_t)j * OW * OH + pix) * 32 + 16 * kh
+                                               : out_img + pix * COUT + j * 32 + 16 * kh;
+                    *(uint4 *)dst = v;
                 }
             }
         }
@@ -140,7 +143,7 @@ void pack_l0(const int8_t *w_okc, int cout, int8_t *dst)
 }
 
 hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream)
+                     int n_images, hipStream_t stream, int out_grouped)
 {
     const int tiles_x = (g.OW + TILE_X - 1) / TILE_X, tiles_y = (g.OH + TILE_Y - 1) / TILE_Y;
     int y_chunks = (4096 + tiles_x * n_images - 1) / (tiles_x * n_images);
@@ -150,7 +153,7 @@ hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
     if (g.COUT == 128) {
         const size_t lds = 5 * 128 * KSTEP + patch_bytes;
         hipLaunchKernelGGL(k_l0<4>, grid, dim3(256), lds, stream, in, out, w.d_w_l0, w.d_bias, g.IW, g.IH,
-                           g.OW, g.OH, tiles_y, y_chunks);
+                           g.OW, g.OH, tiles_y, y_chunks, out_grouped);
     } else
         return hipErrorInvalidValue;
     return hipGetLastError();
@@ -168,14 +171,13 @@ hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
 __global__ __launch_bounds__(256, 2) void k_l7(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                const int8_t *__restrict__ w_l7,
                                                const int8_t *__restrict__ bias, int IW, int IH, int OW,
-                                               int OH, int tiles_x)
+                                               int OH, int tiles_x, int in_grouped)
 {
     constexpr int NQ = 4, CIN = 128;
-    using PG = PatchGeom<NQ>;
     constexpr int WBYTES = 18 * 16 * 64;  // 18 K steps x 16 rows x 64 bytes
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *patch = smem;
-    uint8_t *wl = smem + PG::ALLOC;
+    uint8_t *wl = smem + NQ * SUB_ALLOC;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -183,22 +185,15 @@ __global__ __launch_bounds__(256, 2) void k_l7(const uint8_t *__restrict__ in, u
     const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
     const int Y0 = tile_y * TILE_Y, X0 = tile_x * TILE_X;
 
-    const size_t in_img_bytes = (size_t)IH * IW * CIN;
-    __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(in + (size_t)img * in_img_bytes), 0, (int)in_img_bytes, 0x00020000);
+    const int in_img_bytes = IH * IW * CIN;
+    const uint8_t *in_img = in + (size_t)img * in_img_bytes;
 #pragma unroll
-    for (int r = 0; r < PG::ROUNDS; r++) {
-        const int piece = r * 4 + w;
-        const int gp = piece * 32 + (lane >> 1);
-        const int sub = gp / PATCH_PIX, p = gp - sub * PATCH_PIX;
-        const int ty = p / PATCH_X, tx = p - ty * PATCH_X;
-        const int hlog = (lane & 1) ^ ((p >> 3) & 1);
-        const int iy = Y0 - 1 + ty, ix = X0 - 1 + tx;
-        const bool ok = sub < NQ && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
-        const uint32_t off = ok ? (uint32_t)((iy * IW + ix) * CIN + sub * 32 + hlog * 16) : OOB;
-        if (piece < PG::PIECES)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, LDS_PTR(patch + piece * 1024), 16, off, 0, 0, 0);
-    }
+    for (int sub = 0; sub < NQ; sub++)
+#pragma unroll
+        for (int slot = 0; slot < 3; slot++)
+            load_piece(patch, in_img, in_img_bytes, sub, slot * 4 + w,
+                       piece_src_offset(slot * 4 + w, lane, Y0 - 1, X0 - 1, 1, 0, 0, IW, IH, in_grouped != 0,
+                                        (uint32_t)sub, CIN));
     for (int piece = w; piece < WBYTES / 1024; piece += 4)
         __builtin_amdgcn_global_load_lds(GLB_PTR(w_l7 + piece * 1024 + lane * 16), LDS_PTR(wl + piece * 1024),
                                          16, 0, 0);
@@ -229,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void k_l7(const uint8_t *__restrict__ in, u
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
                     const int p = (2 * w + i + dy) * PATCH_X + 16 * c + m + dx;
-                    const v4i pf = *(const v4i *)(patch + sub * SUB_BYTES + p * 32 + ((((p >> 3) & 1) ^ (kg & 1)) << 4));
+                    const v4i pf = *(const v4i *)(patch + sub * SUB_ALLOC + p * 32 + ((((p >> 3) & 1) ^ (kg & 1)) << 4));
                     acc[i][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf, pf, acc[i][c], 0, 0, 0);
                 }
         }
@@ -269,16 +264,16 @@ void pack_l7(const int8_t *w_okc, int cin, int8_t *dst)
 }
 
 hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream)
+                     int n_images, hipStream_t stream, int in_grouped)
 {
     if (g.CIN != 128 || g.COUT != 3) return hipErrorInvalidValue;
     if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB) return hipErrorInvalidValue;
     const int tiles_x = (g.IW + TILE_X - 1) / TILE_X, tiles_y = (g.IH + TILE_Y - 1) / TILE_Y;
-    const size_t lds = PatchGeom<4>::ALLOC + 18 * 16 * 64;
+    const size_t lds = 4 * SUB_ALLOC + 18 * 16 * 64;
     hipError_t e = hipFuncSetAttribute((const void *)k_l7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_l7, dim3((unsigned)(tiles_x * tiles_y), 1, (unsigned)n_images), dim3(256), lds, stream,
-                       in, out, w.d_w_l7, w.d_bias, g.IW, g.IH, g.OW, g.OH, tiles_x);
+                       in, out, w.d_w_l7, w.d_bias, g.IW, g.IH, g.OW, g.OH, tiles_x, in_grouped);
     return hipGetLastError();
 }
 

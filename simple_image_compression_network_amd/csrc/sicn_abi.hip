@@ -169,8 +169,20 @@ extern "C" int sicn_weights_from_finn_tiles(const sicn_layer_desc *d, const void
 }
 
 // ---- single layers ------------------------------------------------------------------------------
+// Which sides of a layer can use the grouped layout [C/32][H][W][32] (k_common.hpp)?
+static bool can_read_grouped(const sicn_layer_desc &d)
+{
+    const KernelKind k = pick_kernel(d);
+    return k == KK_MFMA_CONV || k == KK_MFMA_DECONV || k == KK_L7_RGB;
+}
+static bool can_write_grouped(const sicn_layer_desc &d)
+{
+    const KernelKind k = pick_kernel(d);
+    return k == KK_MFMA_CONV || k == KK_MFMA_DECONV || k == KK_L0_RGB;
+}
+
 static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream, int want_transposed)
+                     int n_images, hipStream_t stream, int want_transposed, int in_grouped = 0, int out_grouped = 0)
 {
     int rc = sicn_validate_desc(d);
     if (rc) return rc;
@@ -182,10 +194,10 @@ static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint
     const LayerGeom g = geom_of(*d);
     hipError_t e;
     switch (pick_kernel(*d)) {
-    case KK_L0_RGB: e = launch_l0(g, *w, in, out, n_images, stream); break;
-    case KK_L7_RGB: e = launch_l7(g, *w, in, out, n_images, stream); break;
+    case KK_L0_RGB: e = launch_l0(g, *w, in, out, n_images, stream, out_grouped); break;
+    case KK_L7_RGB: e = launch_l7(g, *w, in, out, n_images, stream, in_grouped); break;
     case KK_MFMA_CONV:
-    case KK_MFMA_DECONV: e = launch_mfma(g, *w, in, out, n_images, stream); break;
+    case KK_MFMA_DECONV: e = launch_mfma(g, *w, in, out, n_images, stream, in_grouped, out_grouped); break;
     default: e = launch_generic(g, *w, in, out, n_images, stream); break;
     }
     if (e == hipErrorInvalidValue) return SICN_EINVAL;
@@ -286,12 +298,16 @@ extern "C" int sicn_net_forward(const sicn_net *net_c, int first, int last, cons
     hipStream_t stream = (hipStream_t)hip_stream;
     uint8_t *pp[2] = {(uint8_t *)workspace, (uint8_t *)workspace + slot};
     const uint8_t *cur = in;
+    int cur_grouped = 0;  // the chain's input is always NHWC
     for (int l = first; l <= last; l++) {
         uint8_t *dst = (l == last) ? out : pp[(l - first) & 1];
+        // intermediates nobody outside sees travel in the grouped layout when both neighbours can
+        const int out_grouped = (l < last && l != tap_layer && can_write_grouped(net->descs[l]) &&
+                                 can_read_grouped(net->descs[l + 1])) ? 1 : 0;
         const bool prof = net->profile && net->ev_count[l] < sicn_net::EV_RING;
         if (prof && hipEventRecord(net->ev_begin[(size_t)l * sicn_net::EV_RING + net->ev_count[l]], stream) != hipSuccess)
             return SICN_ENODEV;
-        int rc = run_layer(&net->descs[l], net->weights[l], cur, dst, n_images, stream, -1);
+        int rc = run_layer(&net->descs[l], net->weights[l], cur, dst, n_images, stream, -1, cur_grouped, out_grouped);
         if (rc) return rc;
         if (prof) {
             if (hipEventRecord(net->ev_end[(size_t)l * sicn_net::EV_RING + net->ev_count[l]], stream) != hipSuccess)
@@ -304,6 +320,7 @@ extern "C" int sicn_net_forward(const sicn_net *net_c, int first, int last, cons
                 return SICN_ENODEV;
         }
         cur = dst;
+        cur_grouped = out_grouped;
     }
     (void)in_bytes;
     return SICN_OK;
