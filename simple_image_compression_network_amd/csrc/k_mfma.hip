@@ -88,6 +88,10 @@ __device__ __forceinline__ void mma_step(v16i (&acc)[2][NTJ], const uint8_t *sub
 #pragma unroll
         for (int i = 0; i < 2; i++)
             acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[j], pf[i], acc[i][j], 0, 0, 0);
+    // issue every fragment read before the first MFMA (hipcc otherwise recycles one fragment
+    // register set and exposes an LDS round trip per MFMA pair)
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 + NTJ, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NTJ, 0);
 }
 
 // bias is already in the accumulator: truncate mod 256, relu7, 16 consecutive channels per lane
