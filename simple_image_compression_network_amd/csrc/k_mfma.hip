@@ -33,6 +33,8 @@
 //
 // Tensor layouts: NHWC (ABI) or GROUP = [C/32][H][W][32] (between two layers of a chain), chosen
 // per side by run-time flags; see k_common.hpp.
+#include <cstdlib>
+
 #include "k_common.hpp"
 
 namespace sicn {
@@ -71,27 +73,56 @@ __device__ __forceinline__ void init_acc(v16i (&acc)[2][NTJ], const int8_t *bias
     }
 }
 
+// The operand fragments of one K step: 2 pixel fragments (this wave's two 32-position rows) and
+// NTJ weight fragments.  Two sets live in registers: the MFMAs of step s run on one while the
+// ds_reads of step s+1 fill the other.
 template <int NTJ>
-__device__ __forceinline__ void mma_step(v16i (&acc)[2][NTJ], const uint8_t *sub_patch, const uint8_t *wt,
-                                         const uint32_t (&wrow)[NTJ], int p_lane, int kh, int oy, int ox)
+struct Frags {
+    v4i pf[2];
+    v4i wf[NTJ];
+};
+
+template <int NTJ>
+__device__ __forceinline__ void load_frags(Frags<NTJ> &f, const uint8_t *sub_patch, const uint8_t *wt,
+                                           const uint32_t (&wrow)[NTJ], int p_lane, int kh, int oy, int ox)
 {
-    v4i wf[NTJ], pf[2];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         const int p = p_lane + (i + oy) * PATCH_X + ox;
-        pf[i] = *(const v4i *)(sub_patch + p * 32 + ((((p >> 3) & 1) ^ kh) << 4));
+        f.pf[i] = *(const v4i *)(sub_patch + p * 32 + ((((p >> 3) & 1) ^ kh) << 4));
     }
 #pragma unroll
-    for (int j = 0; j < NTJ; j++) wf[j] = *(const v4i *)(wt + wrow[j]);
+    for (int j = 0; j < NTJ; j++) f.wf[j] = *(const v4i *)(wt + wrow[j]);
+}
+
+// half H of a step's MFMAs: pixel row H against every weight tile
+template <int NTJ, int H>
+__device__ __forceinline__ void mma_half(v16i (&acc)[2][NTJ], const Frags<NTJ> &f)
+{
 #pragma unroll
     for (int j = 0; j < NTJ; j++)
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[j], pf[i], acc[i][j], 0, 0, 0);
-    // issue every fragment read before the first MFMA (hipcc otherwise recycles one fragment
-    // register set and exposes an LDS round trip per MFMA pair)
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 + NTJ, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NTJ, 0);
+        acc[H][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.wf[j], f.pf[H], acc[H][j], 0, 0, 0);
+}
+
+// The software-pipelined K step.  On entry `cur` holds the fragments of step s
+// (read during step s-1) and weight tiles <= s+1 are landed for THIS wave's pieces.
+//   [LDS-DMA issue]  MFMA half 0  | counted vmcnt + s_barrier: tile s+1 (and every patch piece
+//   issued before it) is now visible to all waves | ds_read fragments of step s+1 | MFMA half 1
+// so the barrier and the LDS round trip sit between MFMAs of the same wave instead of behind them.
+template <int NTJ, int VMCNT>
+__device__ __forceinline__ void pipelined_step(v16i (&acc)[2][NTJ], const Frags<NTJ> &cur, Frags<NTJ> &nxt,
+                                               const uint8_t *nxt_sub_patch, const uint8_t *nxt_wt,
+                                               const uint32_t (&wrow)[NTJ], int p_lane, int kh, int nxt_oy,
+                                               int nxt_ox)
+{
+    mma_half<NTJ, 0>(acc, cur);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vmcnt<VMCNT>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_frags<NTJ>(nxt, nxt_sub_patch, nxt_wt, wrow, p_lane, kh, nxt_oy, nxt_ox);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_half<NTJ, 1>(acc, cur);
 }
 
 // bias is already in the accumulator: truncate mod 256, relu7, 16 consecutive channels per lane
@@ -123,11 +154,12 @@ __device__ __forceinline__ void store_tiles(const v16i (&acc)[2][NTJ], uint8_t *
     }
 }
 
-// Everything one K step needs, so that the 25 conv steps can be expanded by template recursion
+// Everything one K step needs, so that the conv steps can be expanded by template recursion
 // (their vmcnt immediates and plane-refresh slots are compile-time functions of the tap index).
 template <int NTJ>
 struct StepCtx {
     v16i (&acc)[2][NTJ];
+    Frags<NTJ> (&fr)[2];
     uint8_t *patch;
     uint8_t *ring;
     const int8_t *wstream;
@@ -145,41 +177,34 @@ __host__ __device__ constexpr int refresh_plane(int t)
 __host__ __device__ constexpr int refresh_slot(int t) { return t < 3 ? t : t < 12 ? t - 9 : t < 18 ? t - 15 : t - 21; }
 __host__ __device__ constexpr int has_refresh(int t) { return refresh_plane((t + 25) % 25) >= 0 ? 1 : 0; }
 
+// Conv: 50 steps = two channel groups (q0, q0+1) per expansion, so that the fragment set of a step
+// is a compile-time function (T & 1) of its index.
 template <int NTJ, int T>
-__device__ __forceinline__ void conv_steps(const StepCtx<NTJ> &c, const uint32_t (&poff)[4][3], int q, uint32_t qstride)
+__device__ __forceinline__ void conv_steps(const StepCtx<NTJ> &c, const uint32_t (&poff)[4][3], int q0, uint32_t qstride)
 {
     constexpr int TB = NTJ * 32 * KSTEP, WR = (TB / 1024 + 3) / 4;
-    constexpr Tap tap = conv_tap(T);
-    constexpr int plane = (tap.ky & 1) * 2 + (tap.kx & 1);
-    const int step = q * 25 + T;
+    constexpr int TT = T % 25;                      // tap index inside the channel group
+    constexpr Tap nxt = conv_tap((T + 1) % 25);     // the step whose fragments are fetched here
+    constexpr int nxt_plane = (nxt.ky & 1) * 2 + (nxt.kx & 1);
+    const int q = q0 + T / 25;
+    const int step = q * 25 + TT;
     // (1) plane refresh: plane 3 takes THIS group's data (it was last used by the previous group's
     //     final taps), planes 0..2 take the NEXT group's as soon as their own taps are done.
     //     A refresh with group == NQ reads past the last group: never consumed.
-    constexpr int rp = refresh_plane(T);
+    constexpr int rp = refresh_plane(TT);
     if constexpr (rp >= 0) {
-        constexpr int slot = refresh_slot(T);
+        constexpr int slot = refresh_slot(TT);
         const int qq = (rp == 3) ? q : q + 1;
         load_piece(c.patch, c.in_img, c.in_img_bytes, rp, slot * 4 + c.w, poff[rp][slot] + (uint32_t)qq * qstride);
     }
-    // (2) weight ring top-up (the stream is padded with PF dummy tiles), (3) MFMAs
+    // (2) weight ring top-up (the stream is padded with PF dummy tiles)
     load_wtile<TB>(c.ring, c.wstream, step + PF, c.lane, c.w);
-    mma_step<NTJ>(c.acc, c.patch + plane * SUB_ALLOC, c.ring + (step % RING) * TB, c.wrow, c.p_lane, c.kh,
-                  tap.ky >> 1, tap.kx >> 1);
-    // (4) publish weight tile step+1 (issued 2 steps ago, before that step's B pieces) and, with
-    //     it, every patch piece issued before it
-    wait_vmcnt<(PF - 1) * WR + has_refresh(T - 1) + has_refresh(T)>();
-    block_barrier();
-    if constexpr (T + 1 < 25) conv_steps<NTJ, T + 1>(c, poff, q, qstride);
-}
-
-template <int NTJ>
-__device__ __forceinline__ void deconv_step(const StepCtx<NTJ> &c, int step, int sub, int oy, int ox)
-{
-    constexpr int TB = NTJ * 32 * KSTEP, WR = (TB / 1024 + 3) / 4;
-    load_wtile<TB>(c.ring, c.wstream, step + PF, c.lane, c.w);
-    mma_step<NTJ>(c.acc, c.patch + sub * SUB_ALLOC, c.ring + (step % RING) * TB, c.wrow, c.p_lane, c.kh, oy, ox);
-    wait_vmcnt<(PF - 1) * WR>();
-    block_barrier();
+    // (3) MFMAs of this step around the barrier that publishes weight tile step+1 (issued 2 steps
+    //     ago, before that step's B pieces) and every patch piece issued before it
+    pipelined_step<NTJ, (PF - 1) * WR + has_refresh(TT - 1) + has_refresh(TT)>(
+        c.acc, c.fr[T & 1], c.fr[(T + 1) & 1], c.patch + nxt_plane * SUB_ALLOC, c.ring + ((step + 1) % RING) * TB,
+        c.wrow, c.p_lane, c.kh, nxt.ky >> 1, nxt.kx >> 1);
+    if constexpr (T + 1 < 50) conv_steps<NTJ, T + 1>(c, poff, q0, qstride);
 }
 
 template <int NQ, int NTJ, bool DECONV, int MINW>
@@ -213,7 +238,9 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_t(
     for (int j = 0; j < NTJ; j++) wrow[j] = (uint32_t)((j * 32 + m) * 32 + ((kh ^ ((m >> 3) & 1)) << 4));
 
     v16i acc[2][NTJ];
-    const StepCtx<NTJ> ctx{acc, patch, ring, wstream, wrow, in_img, in_img_bytes, (2 * w) * PATCH_X + m, kh, lane, w};
+    Frags<NTJ> fr[2];
+    const int p_lane = (2 * w) * PATCH_X + m;
+    const StepCtx<NTJ> ctx{acc, fr, patch, ring, wstream, wrow, in_img, in_img_bytes, p_lane, kh, lane, w};
 
     if constexpr (DECONV) {
         // ---- prologue: the whole patch (NQ channel groups) + PF weight tiles --------------------
@@ -228,24 +255,45 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_t(
         for (int s = 0; s < PF; s++) load_wtile<TB>(ring, wstream, s, lane, w);
         wait_vmcnt<0>();
         block_barrier();
+        load_frags<NTJ>(fr[0], patch, ring, wrow, p_lane, kh, 0, 0);  // step 0: phase (0,0), tap (0,0), group 0
 
+        constexpr int WR = (TB / 1024 + 3) / 4;
         int step = 0;
 #pragma unroll
         for (int ph = 0; ph < 4; ph++) {
             const int py = ph >> 1, px = ph & 1;
             const int nkx = 3 - px, ntap = (3 - py) * nkx;
+            const int npy = (ph + 1) >> 1, npx = (ph + 1) & 1;   // first tap of the next phase
             init_acc<NTJ>(acc, bias, kh);
 #pragma unroll 1
             for (int t = 0; t < ntap; t++) {
                 const int iy = t / nkx, ix = t - iy * nkx;
+                // coordinates of the tap after this one (for the last group's prefetch)
+                int noy, nox;
+                if (t + 1 < ntap) {
+                    const int t1 = t + 1, iy1 = t1 / nkx;
+                    noy = iy1 + py;
+                    nox = t1 - iy1 * nkx + px;
+                } else {
+                    noy = npy;
+                    nox = npx;
+                }
 #pragma unroll
-                for (int q = 0; q < NQ; q++) deconv_step<NTJ>(ctx, step + q, q, iy + py, ix + px);
+                for (int q = 0; q < NQ; q++) {
+                    load_wtile<TB>(ring, wstream, step + q + PF, lane, w);
+                    const bool last = (q == NQ - 1);
+                    pipelined_step<NTJ, (PF - 1) * WR>(acc, fr[q & 1], fr[(q + 1) & 1],
+                                                       patch + (last ? 0 : q + 1) * SUB_ALLOC,
+                                                       ring + ((step + q + 1) % RING) * TB, wrow, p_lane, kh,
+                                                       last ? noy : iy + py, last ? nox : ix + px);
+                }
                 step += NQ;
             }
             if (ph == 3) wait_vmcnt<0>();  // the padded tail of the weight prefetch must land before exit
             store_tiles<NTJ>(acc, out_img, OW, OH, MW, MH, Y0, X0, w, m, kh, true, py, px, out_grouped != 0);
         }
     } else {
+        static_assert(DECONV || NQ % 2 == 0, "conv walks channel groups in pairs");
         // ---- per-lane source offsets of the 4 planes x 3 refresh slots (channel group 0) --------
         uint32_t poff[4][3];
 #pragma unroll
@@ -265,10 +313,11 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_t(
         for (int s = 0; s < PF; s++) load_wtile<TB>(ring, wstream, s, lane, w);
         wait_vmcnt<0>();
         block_barrier();
+        load_frags<NTJ>(fr[0], patch, ring, wrow, p_lane, kh, 0, 0);  // step 0: tap (0,0) of plane 0
 
         init_acc<NTJ>(acc, bias, kh);
 #pragma unroll 1
-        for (int q = 0; q < NQ; q++) conv_steps<NTJ, 0>(ctx, poff, q, qstride);
+        for (int q0 = 0; q0 < NQ; q0 += 2) conv_steps<NTJ, 0>(ctx, poff, q0, qstride);
         wait_vmcnt<0>();
         store_tiles<NTJ>(acc, out_img, OW, OH, MW, MH, Y0, X0, w, m, kh, false, 0, 0, out_grouped != 0);
     }
@@ -277,14 +326,12 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_t(
 // Explicit instantiations: the host stubs of a __global__ template that is only named inside
 // another template are not emitted by hipcc (ROCm 7.2) otherwise.
 #define SICN_INST(NQ, NTJ, D)                                                                               \
-    template __global__ void k_mfma_t<NQ, NTJ, D, (NTJ <= 4 ? 2 : 1)>(                                      \
+    template __global__ void k_mfma_t<NQ, NTJ, D, ((NTJ <= 4 && NQ <= 4) ? 2 : 1)>(                                      \
         const uint8_t *__restrict__, uint8_t *__restrict__, const int8_t *__restrict__,                     \
         const int8_t *__restrict__, int, int, int, int, int, int, int, int, int);
 SICN_INST(4, 4, true)
 SICN_INST(6, 4, true)
-SICN_INST(4, 6, true)
 SICN_INST(4, 4, false)
-SICN_INST(6, 4, false)
 SICN_INST(4, 6, false)
 #undef SICN_INST
 
@@ -293,10 +340,11 @@ static hipError_t launch_one(const LayerGeom &g, const sicn_weights &w, const ui
                              int n_images, hipStream_t stream, int in_grouped, int out_grouped)
 {
     constexpr int NSUB = DECONV ? NQ : 4;
-    constexpr int MINW = (NTJ <= 4 ? 2 : 1);
+    constexpr int MINW = ((NTJ <= 4 && NQ <= 4) ? 2 : 1);
     const int MW = DECONV ? g.IW : g.OW, MH = DECONV ? g.IH : g.OH;
     const int tiles_x = (MW + TILE_X - 1) / TILE_X, tiles_y = (MH + TILE_Y - 1) / TILE_Y;
-    const size_t lds = (size_t)NSUB * SUB_ALLOC + (size_t)RING * NTJ * 32 * KSTEP;
+    size_t lds = (size_t)NSUB * SUB_ALLOC + (size_t)RING * NTJ * 32 * KSTEP;
+    if (const char *x = getenv("SICN_DEBUG_EXTRA_LDS")) lds += (size_t)atoi(x);  // occupancy experiments only
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mfma_t<NQ, NTJ, DECONV, MINW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -306,9 +354,10 @@ static hipError_t launch_one(const LayerGeom &g, const sicn_weights &w, const ui
     return hipGetLastError();
 }
 
-bool mfma_supported(int cin, int cout)
+bool mfma_supported(int cin, int cout, int transposed)
 {
-    return (cin == 128 && (cout == 128 || cout == 192)) || (cin == 192 && cout == 128);
+    if (transposed) return (cin == 128 || cin == 192) && cout == 128;
+    return cin == 128 && (cout == 128 || cout == 192);
 }
 
 hipError_t launch_mfma(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
@@ -318,10 +367,8 @@ hipError_t launch_mfma(const LayerGeom &g, const sicn_weights &w, const uint8_t 
     if (g.transposed) {
         if (g.CIN == 128 && g.COUT == 128) return launch_one<4, 4, true>(g, w, in, out, n_images, stream, in_grouped, out_grouped);
         if (g.CIN == 192 && g.COUT == 128) return launch_one<6, 4, true>(g, w, in, out, n_images, stream, in_grouped, out_grouped);
-        if (g.CIN == 128 && g.COUT == 192) return launch_one<4, 6, true>(g, w, in, out, n_images, stream, in_grouped, out_grouped);
     } else {
         if (g.CIN == 128 && g.COUT == 128) return launch_one<4, 4, false>(g, w, in, out, n_images, stream, in_grouped, out_grouped);
-        if (g.CIN == 192 && g.COUT == 128) return launch_one<6, 4, false>(g, w, in, out, n_images, stream, in_grouped, out_grouped);
         if (g.CIN == 128 && g.COUT == 192) return launch_one<4, 6, false>(g, w, in, out, n_images, stream, in_grouped, out_grouped);
     }
     return hipErrorInvalidValue;

@@ -59,7 +59,7 @@ KernelKind pick_kernel(const sicn_layer_desc &d)
     if (g_force_generic) return KK_GENERIC;
     if (!d.transposed && d.IFM_CH == 3 && d.OFM_CH == 128) return KK_L0_RGB;
     if (d.transposed && d.IFM_CH == 128 && d.OFM_CH == 3) return KK_L7_RGB;
-    if (mfma_supported(d.IFM_CH, d.OFM_CH)) return d.transposed ? KK_MFMA_DECONV : KK_MFMA_CONV;
+    if (mfma_supported(d.IFM_CH, d.OFM_CH, d.transposed)) return d.transposed ? KK_MFMA_DECONV : KK_MFMA_CONV;
     return KK_GENERIC;
 }
 }  // namespace sicn
@@ -143,7 +143,7 @@ extern "C" int sicn_weights_from_finn_tiles(const sicn_layer_desc *d, const void
         ok = ok && upload(b.data(), b.size(), &w->d_bias);
     }
     try {
-        if (ok && mfma_supported(cin, cout)) {
+        if (ok && mfma_supported(cin, cout, d->transposed)) {
             std::vector<int8_t> s(mfma_stream_bytes(cin, cout));
             pack_mfma_stream(w_okc.data(), cin, cout, d->transposed, s.data());
             w->mfma_steps = mfma_stream_steps(cin);

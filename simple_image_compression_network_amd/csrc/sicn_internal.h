@@ -67,7 +67,7 @@ hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
 size_t mfma_stream_bytes(int cin, int cout);
 int mfma_stream_steps(int cin);
 void pack_mfma_stream(const int8_t *w_okc, int cin, int cout, int transposed, int8_t *dst);
-bool mfma_supported(int cin, int cout);
+bool mfma_supported(int cin, int cout, int transposed);
 
 size_t l0_bytes(int cout);
 void pack_l0(const int8_t *w_okc, int cout, int8_t *dst);
