@@ -261,3 +261,19 @@ def test_layer_timing_hooks(api):
     assert cnt == [3] * 8 and all(m > 0 for m in ms)
     ms, cnt = net.layer_ms()
     assert cnt == [0] * 8
+
+
+def test_cpp_testbench_mirrors_reference_test():
+    """tests/cpp/tb_eight_layers_net.cpp = the reference's test_eight_layers_net (conv3_nonsquare_tb.cpp:
+    781-1132) over the C++ veneer include/sicn_hls.hpp: all-ones stimulus (reduced size so the naive golden
+    model finishes in seconds) and a seeded random image; exit code is the verdict, as in the reference."""
+    import subprocess
+    from conftest import ROOT
+    exe = ROOT / "tests" / "cpp" / "tb_eight_layers_net"
+    params = ROOT / "simple_image_compression_network_amd" / "data" / "param_weights.bin"
+    assert exe.exists() and params.exists(), "run __graft_entry__.build() first"
+    for args in (["192", "128"], ["96", "80", "7"]):
+        r = subprocess.run([str(exe), str(params)] + args, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert "Image # 0 passed the testing." in r.stdout
+        assert "conv2d_layer0: passed" in r.stdout and "deconv2d_layer4: passed" in r.stdout
