@@ -19,9 +19,60 @@ namespace sicn {
 // Same work split as k_mfma: 8 x 32 output tile, wave w = rows 2w, 2w+1, all output channels.
 // =============================================================================================
 constexpr int L0_ROWS = 2 * TILE_Y + 3;       // 19 input rows per tile
-constexpr int L0_COLS = 2 * TILE_X + 6;       // 70 pixel slots per row (lane 31, kh=1 reads 62+4..69)
-constexpr int L0_PITCH = L0_COLS * 4;         // 280 bytes, 8-byte aligned rows
+constexpr int L0_QUADS = 18;                  // 4-pixel groups per row: 72 slots >= 2*31+4+4
+constexpr int L0_PITCH = L0_QUADS * 16;       // 288 bytes, 16-byte aligned rows
+constexpr int L0_NQUAD = L0_ROWS * L0_QUADS;  // 342 quads per tile, <= 2 per thread
+constexpr int L0_PATCH = L0_ROWS * L0_PITCH;  // 5472 bytes
 
+// One quad = 4 consecutive input pixels (12 bytes at an arbitrary byte alignment) of one patch row,
+// fetched as 4 aligned dwords through a buffer descriptor (reads past either end of the image
+// return 0) and re-aligned in registers.
+struct L0Quad {
+    uint32_t d[4];
+};
+
+__device__ __forceinline__ void l0_quad_fetch(L0Quad &q, const uint8_t *tensor, int tensor_bytes4, int img_byte0,
+                                              int quad, int Y0, int X0, int IW, int IH)
+{
+    // descriptor over the WHOLE input tensor (its base is allocator-aligned; an image base need
+    // not be 4-byte aligned), size rounded up to a dword so the last partial dword is readable
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)tensor, 0, tensor_bytes4, 0x00020000);
+    const int r = quad / L0_QUADS, g = quad - r * L0_QUADS;
+    const int iy = 2 * Y0 - 2 + r, ix0 = 2 * X0 - 2 + 4 * g;
+    const bool row_ok = quad < L0_NQUAD && iy >= 0 && iy < IH;
+    const int a = (img_byte0 + (iy * IW + ix0) * 3) & ~3;   // negative only left of the very first pixel
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int o = a + 4 * k;
+        q.d[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (row_ok && o >= 0) ? (uint32_t)o : OOB, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void l0_quad_store(const L0Quad &q, uint8_t *patch, int img_byte0, int quad, int Y0, int X0,
+                                              int IW, int IH)
+{
+    if (quad >= L0_NQUAD) return;
+    const int r = quad / L0_QUADS, g = quad - r * L0_QUADS;
+    const int iy = 2 * Y0 - 2 + r, ix0 = 2 * X0 - 2 + 4 * g;
+    const uint32_t sh = (uint32_t)(img_byte0 + (iy * IW + ix0) * 3) & 3u;
+    // 12 payload bytes starting `sh` bytes into d[0..3]
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(q.d[1], q.d[0], sh);
+    const uint32_t w1 = __builtin_amdgcn_alignbyte(q.d[2], q.d[1], sh);
+    const uint32_t w2 = __builtin_amdgcn_alignbyte(q.d[3], q.d[2], sh);
+    const bool row_ok = iy >= 0 && iy < IH;
+    uint4 v;
+    v.x = (row_ok && ix0 + 0 >= 0 && ix0 + 0 < IW) ? (w0 & 0xFFFFFFu) : 0u;
+    v.y = (row_ok && ix0 + 1 >= 0 && ix0 + 1 < IW) ? (__builtin_amdgcn_alignbyte(w1, w0, 3) & 0xFFFFFFu) : 0u;
+    v.z = (row_ok && ix0 + 2 >= 0 && ix0 + 2 < IW) ? (__builtin_amdgcn_alignbyte(w2, w1, 2) & 0xFFFFFFu) : 0u;
+    v.w = (row_ok && ix0 + 3 >= 0 && ix0 + 3 < IW) ? (w2 >> 8) : 0u;
+    *(uint4 *)(patch + quad * 16) = v;
+}
+
+// Persistent over a vertical strip of tiles.  Per tile: the NEXT tile's pixels are fetched into
+// registers before the MFMAs of the current tile and written to the other LDS patch after them
+// (issue early / write late), and the output stores of a tile are issued last, so the only
+// vmcnt(0) of an iteration waits for loads that had a whole MFMA phase to land and for stores of
+// the previous iteration.
 template <int NTJ>
 __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                const int8_t *__restrict__ w_l0,
@@ -31,10 +82,9 @@ __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, u
     constexpr int COUT = NTJ * 32;
     constexpr int TB = COUT * KSTEP;
     constexpr int WBYTES = 5 * TB;
-    constexpr int PATCH_BYTES = ((L0_ROWS * L0_PITCH + 15) / 16) * 16;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *wl = smem;
-    uint32_t *patch = (uint32_t *)(smem + WBYTES);
+    uint8_t *patch0 = smem + WBYTES;  // two patches of L0_PATCH bytes (16-byte multiples)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -43,33 +93,38 @@ __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, u
     const int X0 = blockIdx.x * TILE_X;
     const int ty_per = (tiles_y + y_chunks - 1) / y_chunks;
     const int ty_begin = blockIdx.y * ty_per, ty_end = min(tiles_y, ty_begin + ty_per);
-
     if (ty_begin >= ty_end) return;  // before any LDS-DMA is issued
+
     // weights: 5 tiles of [COUT][32 B] (row permutation + half swizzle as in k_mfma), linear copy
     for (int piece = w; piece < WBYTES / 1024; piece += 4)
         __builtin_amdgcn_global_load_lds(GLB_PTR(w_l0 + piece * 1024 + lane * 16), LDS_PTR(wl + piece * 1024),
                                          16, 0, 0);
-
     uint32_t wrow[NTJ];
 #pragma unroll
     for (int j = 0; j < NTJ; j++) wrow[j] = (uint32_t)((j * 32 + m) * 32 + ((kh ^ ((m >> 3) & 1)) << 4));
 
-    const uint8_t *im = in + (size_t)img * IH * IW * 3;
-    for (int tile_y = ty_begin; tile_y < ty_end; tile_y++) {
+    const int im_bytes = IH * IW * 3;
+    const int img_byte0 = img * im_bytes;                       // launch_l0 guarantees the tensor is < 2 GiB
+    const int tensor_bytes4 = ((int)gridDim.z * im_bytes + 3) & ~3;
+    uint8_t *out_img = out + (size_t)img * OH * OW * COUT;
+
+    L0Quad qa, qb;
+    l0_quad_fetch(qa, in, tensor_bytes4, img_byte0, tid, ty_begin * TILE_Y, X0, IW, IH);
+    l0_quad_fetch(qb, in, tensor_bytes4, img_byte0, tid + 256, ty_begin * TILE_Y, X0, IW, IH);
+    wait_vmcnt<0>();
+    l0_quad_store(qa, patch0, img_byte0, tid, ty_begin * TILE_Y, X0, IW, IH);
+    l0_quad_store(qb, patch0, img_byte0, tid + 256, ty_begin * TILE_Y, X0, IW, IH);
+    block_barrier();
+
+    int buf = 0;
+    for (int tile_y = ty_begin; tile_y < ty_end; tile_y++, buf ^= 1) {
         const int Y0 = tile_y * TILE_Y;
-        // ---- fill the RGBX patch: slot (r, c) = input pixel (2*Y0 - 2 + r, 2*X0 - 2 + c) ----
-        __syncthreads();  // previous tile's readers are done (also drains the weight DMA once)
-        for (int s = tid; s < L0_ROWS * L0_COLS; s += 256) {
-            const int r = s / L0_COLS, c = s - r * L0_COLS;
-            const int iy = 2 * Y0 - 2 + r, ix = 2 * X0 - 2 + c;
-            uint32_t v = 0;
-            if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) {
-                const uint8_t *p = im + ((size_t)iy * IW + ix) * 3;
-                v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
-            }
-            patch[s] = v;
+        const uint8_t *patch = patch0 + buf * L0_PATCH;
+        const bool more = tile_y + 1 < ty_end;
+        if (more) {  // issue early
+            l0_quad_fetch(qa, in, tensor_bytes4, img_byte0, tid, Y0 + TILE_Y, X0, IW, IH);
+            l0_quad_fetch(qb, in, tensor_bytes4, img_byte0, tid + 256, Y0 + TILE_Y, X0, IW, IH);
         }
-        __syncthreads();
 
         v16i acc[2][NTJ];
 #pragma unroll
@@ -89,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, u
             for (int j = 0; j < NTJ; j++) wf[j] = *(const v4i *)(wl + ky * TB + wrow[j]);
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                const uint8_t *src = (const uint8_t *)patch + (2 * (2 * w + i) + ky) * L0_PITCH + 8 * m + 16 * kh;
+                const uint8_t *src = patch + (2 * (2 * w + i) + ky) * L0_PITCH + 8 * m + 16 * kh;
                 const uint2 lo = *(const uint2 *)src, hi = *(const uint2 *)(src + 8);
                 pf[i] = v4i{(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
             }
@@ -99,11 +154,16 @@ __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, u
                 for (int i = 0; i < 2; i++)
                     acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[j], pf[i], acc[i][j], 0, 0, 0);
         }
+        if (more) {  // write late: into the patch nobody reads during this iteration
+            wait_vmcnt<0>();
+            uint8_t *nxt = patch0 + (buf ^ 1) * L0_PATCH;
+            l0_quad_store(qa, nxt, img_byte0, tid, Y0 + TILE_Y, X0, IW, IH);
+            l0_quad_store(qb, nxt, img_byte0, tid + 256, Y0 + TILE_Y, X0, IW, IH);
+        }
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int gy = Y0 + 2 * w + i, gx = X0 + m;
             if (gy < OH && gx < OW) {
-                uint8_t *out_img = out + (size_t)img * OH * OW * COUT;
                 const size_t pix = (size_t)gy * OW + gx;
 #pragma unroll
                 for (int j = 0; j < NTJ; j++) {
@@ -119,6 +179,7 @@ __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, u
                 }
             }
         }
+        block_barrier();  // next patch complete, this patch free (raw barrier: stores stay in flight)
     }
 }
 
@@ -149,9 +210,9 @@ hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
     int y_chunks = (4096 + tiles_x * n_images - 1) / (tiles_x * n_images);
     y_chunks = y_chunks < 1 ? 1 : (y_chunks > tiles_y ? tiles_y : y_chunks);
     dim3 grid((unsigned)tiles_x, (unsigned)y_chunks, (unsigned)n_images);
-    const int patch_bytes = ((L0_ROWS * L0_PITCH + 15) / 16) * 16;
+    if ((size_t)g.IH * g.IW * 3 * (size_t)n_images + 4 >= (size_t)OOB) return hipErrorInvalidValue;
     if (g.COUT == 128) {
-        const size_t lds = 5 * 128 * KSTEP + patch_bytes;
+        const size_t lds = 5 * 128 * KSTEP + 2 * L0_PATCH;
         hipLaunchKernelGGL(k_l0<4>, grid, dim3(256), lds, stream, in, out, w.d_w_l0, w.d_bias, g.IW, g.IH,
                            g.OW, g.OH, tiles_y, y_chunks, out_grouped);
     } else
@@ -166,83 +227,134 @@ hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
 // phase).  v_mfma_i32_16x16x64_i8: A = W' (16 rows x 64 K bytes), B = 16 positions, 18 K steps
 // (9 taps x two 64-channel halves).  Output tile: lane (position l&15, phase l>>4) holds the 3
 // channel bytes of out[2y+py][2x+px].
-// The input patch uses the sub-patch format of k_mfma's deconv path (4 groups of 32 channels).
+//   * W' (18 KB) is held in REGISTERS (72 VGPRs) for the whole vertical strip a workgroup walks.
+//   * LDS patch: two regions (K-group parity kg&1), each [position][4 chunks x 16 B] with chunk
+//     c2 = 2*half + (kg>>1) stored at c2 ^ ((p>>2)&3): a 16-lane ds_read_b128 group covers 16
+//     distinct positions at ONE c2, i.e. 16 distinct 16-byte slots of a 256-byte LDS row.
+//   * RGB output is transposed through a 768-byte per-wave LDS staging tile and stored as dwords.
 // =============================================================================================
+constexpr int L7_REGION_PIECES = 22;                    // 340 positions x 64 B = 21760 B
+constexpr int L7_REGION = L7_REGION_PIECES * 1024;
+constexpr int L7_STAGE = 4 * 192;                       // 4 output rows x 64 pixels x 3 B per wave
+
 __global__ __launch_bounds__(256, 2) void k_l7(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                const int8_t *__restrict__ w_l7,
                                                const int8_t *__restrict__ bias, int IW, int IH, int OW,
-                                               int OH, int tiles_x, int in_grouped)
+                                               int OH, int tiles_y, int y_chunks, int in_grouped)
 {
-    constexpr int NQ = 4, CIN = 128;
-    constexpr int WBYTES = 18 * 16 * 64;  // 18 K steps x 16 rows x 64 bytes
+    constexpr int CIN = 128;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *patch = smem;
-    uint8_t *wl = smem + NQ * SUB_ALLOC;
+    uint8_t *stage = smem + 2 * L7_REGION;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int img = blockIdx.z;
-    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
-    const int Y0 = tile_y * TILE_Y, X0 = tile_x * TILE_X;
-
-    const int in_img_bytes = IH * IW * CIN;
-    const uint8_t *in_img = in + (size_t)img * in_img_bytes;
-#pragma unroll
-    for (int sub = 0; sub < NQ; sub++)
-#pragma unroll
-        for (int slot = 0; slot < 3; slot++)
-            load_piece(patch, in_img, in_img_bytes, sub, slot * 4 + w,
-                       piece_src_offset(slot * 4 + w, lane, Y0 - 1, X0 - 1, 1, 0, 0, IW, IH, in_grouped != 0,
-                                        (uint32_t)sub, CIN));
-    for (int piece = w; piece < WBYTES / 1024; piece += 4)
-        __builtin_amdgcn_global_load_lds(GLB_PTR(w_l7 + piece * 1024 + lane * 16), LDS_PTR(wl + piece * 1024),
-                                         16, 0, 0);
-    wait_vmcnt<0>();
-    block_barrier();
+    const int X0 = blockIdx.x * TILE_X;
+    const int ty_per = (tiles_y + y_chunks - 1) / y_chunks;
+    const int ty_begin = blockIdx.y * ty_per, ty_end = min(tiles_y, ty_begin + ty_per);
+    if (ty_begin >= ty_end) return;
 
     // lane roles in v_mfma_i32_16x16x64_i8: A row / B column = lane & 15, K bytes 16*(lane>>4)..+15
     const int m = lane & 15, kg = lane >> 4;
-    // wave w owns rows 2w, 2w+1; each row = two 16-position column tiles
-    v4i acc[2][2];
-    {
-        // C rows 4*kg + r  ->  phase kg, channel r (r == 3 is a dummy row)
-        const int b0 = bias[0], b1 = bias[1], b2 = bias[2];
+    v4i wf[18];
+#pragma unroll
+    for (int s = 0; s < 18; s++) wf[s] = *(const v4i *)(w_l7 + (s * 16 + m) * 64 + kg * 16);
+    const int b0 = bias[0], b1 = bias[1], b2 = bias[2];
+
+    const int in_img_bytes = IH * IW * CIN;
+    const uint8_t *in_img = in + (size_t)img * in_img_bytes;
+    uint8_t *out_img = out + (size_t)img * OH * OW * 3;
+    const int py = kg >> 1, px = kg & 1;
+    uint8_t *my_stage = stage + w * L7_STAGE;
+    const bool fast_rows = ((OW * 3) & 3) == 0 && X0 + TILE_X <= IW;
+
+    for (int tile_y = ty_begin; tile_y < ty_end; tile_y++) {
+        const int Y0 = tile_y * TILE_Y;
+        block_barrier();  // every wave is done reading the previous patch
+        {
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)in_img, 0, in_img_bytes, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < 2 * L7_REGION_PIECES / 4; r++) {
+                const int piece = r * 4 + w;                    // 44 pieces, 11 per wave
+                const int region = piece / L7_REGION_PIECES, k = piece - region * L7_REGION_PIECES;
+                const int p = k * 16 + (lane >> 2);
+                const int ty = p / PATCH_X, tx = p - ty * PATCH_X;
+                const int c2 = (lane & 3) ^ ((p >> 2) & 3);     // channel group of 32 = 2*half + (kg>>1)
+                const int iy = Y0 - 1 + ty, ix = X0 - 1 + tx;
+                const bool ok = p < PATCH_PIX && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
+                const uint32_t off = ok ? pix_group_offset(in_grouped != 0, (uint32_t)(iy * IW + ix), (uint32_t)c2, CIN,
+                                                           (uint32_t)(IW * IH)) + 16u * region
+                                        : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(patch + piece * 1024), 16, off, 0, 0, 0);
+            }
+        }
+        wait_vmcnt<0>();
+        block_barrier();
+
+        // wave w owns rows 2w, 2w+1; each row = two 16-position column tiles
+        v4i acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int c = 0; c < 2; c++) acc[i][c] = v4i{b0, b1, b2, 0};
-    }
-#pragma unroll 1
-    for (int tap = 0; tap < 9; tap++) {
-        const int dy = tap / 3, dx = tap - dy * 3;
+            for (int c = 0; c < 2; c++) acc[i][c] = v4i{b0, b1, b2, 0};  // C row 4*kg + r = phase kg, channel r
+        const uint8_t *reg = patch + (kg & 1) * L7_REGION;
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const v4i wf = *(const v4i *)(wl + ((tap * 2 + half) * 16 + m) * 64 + kg * 16);
-            const int sub = 2 * half + (kg >> 1);
+        for (int tap = 0; tap < 9; tap++) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int c2 = 2 * half + (kg >> 1);
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        const int p = (2 * w + i + dy) * PATCH_X + 16 * c + m + dx;
+                        const v4i pf = *(const v4i *)(reg + p * 64 + ((c2 ^ ((p >> 2) & 3)) << 4));
+                        acc[i][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[tap * 2 + half], pf, acc[i][c], 0, 0, 0);
+                    }
+            }
+        }
+        // ---- epilogue ----------------------------------------------------------------------
+        if (fast_rows) {
+            // stage [4 rows = 2i+py][64 pixels = 2*(16c+m)+px][3] and write rows as dwords
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
-                    const int p = (2 * w + i + dy) * PATCH_X + 16 * c + m + dx;
-                    const v4i pf = *(const v4i *)(patch + sub * SUB_ALLOC + p * 32 + ((((p >> 3) & 1) ^ (kg & 1)) << 4));
-                    acc[i][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf, pf, acc[i][c], 0, 0, 0);
+                    const uint32_t v = pack4_relu7(acc[i][c][0], acc[i][c][1], acc[i][c][2], 0);
+                    uint8_t *d = my_stage + (2 * i + py) * 192 + (2 * (16 * c + m) + px) * 3;
+                    d[0] = (uint8_t)v;
+                    d[1] = (uint8_t)(v >> 8);
+                    d[2] = (uint8_t)(v >> 16);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private staging: no barrier needed
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int idx = k * 64 + lane;                   // dword index in the 4 x 48 tile
+                const int row = idx / 48, col = idx - row * 48;
+                const int gy = Y0 + 2 * w + (row >> 1);
+                if (gy < IH) {
+                    const uint32_t v = *(const uint32_t *)(my_stage + row * 192 + col * 4);
+                    *(uint32_t *)(out_img + ((size_t)(2 * (Y0 + 2 * w) + row) * OW + 2 * X0) * 3 + col * 4) = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const int gy = Y0 + 2 * w + i, gx = X0 + 16 * c + m;
+                    if (gy < IH && gx < IW) {
+                        const uint32_t v = pack4_relu7(acc[i][c][0], acc[i][c][1], acc[i][c][2], 0);
+                        uint8_t *dst = out_img + ((size_t)(2 * gy + py) * OW + 2 * gx + px) * 3;
+                        dst[0] = (uint8_t)v;
+                        dst[1] = (uint8_t)(v >> 8);
+                        dst[2] = (uint8_t)(v >> 16);
+                    }
                 }
         }
     }
-    const int py = kg >> 1, px = kg & 1;
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const int gy = Y0 + 2 * w + i, gx = X0 + 16 * c + m;
-            if (gy < IH && gx < IW) {
-                const uint32_t v = pack4_relu7(acc[i][c][0], acc[i][c][1], acc[i][c][2], 0);
-                uint8_t *dst = out + (((size_t)img * OH + 2 * gy + py) * OW + 2 * gx + px) * 3;
-                dst[0] = (uint8_t)v;
-                dst[1] = (uint8_t)(v >> 8);
-                dst[2] = (uint8_t)(v >> 16);
-            }
-        }
 }
 
 size_t l7_bytes(int cin) { return (size_t)18 * 16 * 64 * (cin / 128); }
@@ -269,11 +381,13 @@ hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
     if (g.CIN != 128 || g.COUT != 3) return hipErrorInvalidValue;
     if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB) return hipErrorInvalidValue;
     const int tiles_x = (g.IW + TILE_X - 1) / TILE_X, tiles_y = (g.IH + TILE_Y - 1) / TILE_Y;
-    const size_t lds = 4 * SUB_ALLOC + 18 * 16 * 64;
+    int y_chunks = (6144 + tiles_x * n_images - 1) / (tiles_x * n_images);
+    y_chunks = y_chunks < 1 ? 1 : (y_chunks > tiles_y ? tiles_y : y_chunks);
+    const size_t lds = 2 * L7_REGION + 4 * L7_STAGE;
     hipError_t e = hipFuncSetAttribute((const void *)k_l7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_l7, dim3((unsigned)(tiles_x * tiles_y), 1, (unsigned)n_images), dim3(256), lds, stream,
-                       in, out, w.d_w_l7, w.d_bias, g.IW, g.IH, g.OW, g.OH, tiles_x, in_grouped);
+    hipLaunchKernelGGL(k_l7, dim3((unsigned)tiles_x, (unsigned)y_chunks, (unsigned)n_images), dim3(256), lds, stream,
+                       in, out, w.d_w_l7, w.d_bias, g.IW, g.IH, g.OW, g.OH, tiles_y, y_chunks, in_grouped);
     return hipGetLastError();
 }
 
