@@ -85,9 +85,12 @@ class DeviceWeights:
         return self._h
 
     def __del__(self):
-        if getattr(self, "_h", None) and _lib._lib is not None:
-            _lib._lib.sicn_weights_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None) and _lib._lib is not None:
+                _lib._lib.sicn_weights_free(self._h)
+                self._h = None
+        except Exception:       # interpreter shutdown: module globals may already be gone
+            pass
 
 
 def _as_device(desc, weights, bias) -> DeviceWeights:
@@ -174,9 +177,12 @@ class EightLayersNet:
         self._ws_images = 0
 
     def __del__(self):
-        if getattr(self, "_h", None) and _lib._lib is not None:
-            _lib._lib.sicn_net_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None) and _lib._lib is not None:
+                _lib._lib.sicn_net_free(self._h)
+                self._h = None
+        except Exception:       # interpreter shutdown
+            pass
 
     def workspace(self, n_images: int):
         import torch

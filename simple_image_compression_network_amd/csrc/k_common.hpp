@@ -35,12 +35,19 @@ __device__ __forceinline__ void block_barrier()
     asm volatile("" ::: "memory");
 }
 
-// relu7((v) mod 256) for four accumulators, packed little-endian into one dword.
+// relu7((v) mod 256) for four accumulators, packed little-endian into one dword — 5 VALU ops:
+// the low byte of each accumulator is moved to the HIGH byte of a 16-bit lane (v_perm_b32), so the
+// byte's sign is the lane's sign and v_pk_max_i16(x, 0) is the ReLU; a last v_perm_b32 gathers the
+// four high bytes.
+typedef short v2s __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack4_relu7(int a, int b, int c, int d)
 {
-    int sa = max((int)(int8_t)a, 0), sb = max((int)(int8_t)b, 0);
-    int sc = max((int)(int8_t)c, 0), sd = max((int)(int8_t)d, 0);
-    return (uint32_t)sa | ((uint32_t)sb << 8) | ((uint32_t)sc << 16) | ((uint32_t)sd << 24);
+    const uint32_t ab = __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x040c000cu);  // [0, a.b0, 0, b.b0]
+    const uint32_t cd = __builtin_amdgcn_perm((uint32_t)d, (uint32_t)c, 0x040c000cu);
+    const v2s z = {0, 0};
+    const v2s mab = __builtin_elementwise_max(__builtin_bit_cast(v2s, ab), z);
+    const v2s mcd = __builtin_elementwise_max(__builtin_bit_cast(v2s, cd), z);
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, mcd), __builtin_bit_cast(uint32_t, mab), 0x07050301u);
 }
 
 // Tensor layouts.  NHWC  : [H][W][C]           (the ABI layout = the reference's stream bytes)

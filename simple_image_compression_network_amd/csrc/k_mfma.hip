@@ -109,20 +109,37 @@ __device__ __forceinline__ void mma_half(v16i (&acc)[2][NTJ], const Frags<NTJ> &
 //   [LDS-DMA issue]  MFMA half 0  | counted vmcnt + s_barrier: tile s+1 (and every patch piece
 //   issued before it) is now visible to all waves | ds_read fragments of step s+1 | MFMA half 1
 // so the barrier and the LDS round trip sit between MFMAs of the same wave instead of behind them.
-template <int NTJ, int VMCNT>
-__device__ __forceinline__ void pipelined_step(v16i (&acc)[2][NTJ], const Frags<NTJ> &cur, Frags<NTJ> &nxt,
-                                               const uint8_t *nxt_sub_patch, const uint8_t *nxt_wt,
-                                               const uint32_t (&wrow)[NTJ], int p_lane, int kh, int nxt_oy,
-                                               int nxt_ox)
+// VARIANT 1 (pipelined): MFMA half 0 | vmcnt + barrier | ds_read fragments of step s+1 | MFMA half 1.
+// VARIANT 0 (simple)   : ds_read fragments of step s | all MFMAs | vmcnt + barrier.
+// Both are kept for in-process A/B runs (SICN_MFMA_VARIANT): on a power-limited chip the simpler
+// stream is not necessarily the slower one.
+template <int NTJ, int VMCNT, int VARIANT>
+__device__ __forceinline__ void k_step(v16i (&acc)[2][NTJ], Frags<NTJ> &cur, Frags<NTJ> &nxt,
+                                       const uint8_t *cur_sub_patch, const uint8_t *cur_wt, int cur_oy, int cur_ox,
+                                       const uint8_t *nxt_sub_patch, const uint8_t *nxt_wt, int nxt_oy, int nxt_ox,
+                                       const uint32_t (&wrow)[NTJ], int p_lane, int kh)
 {
-    mma_half<NTJ, 0>(acc, cur);
-    __builtin_amdgcn_sched_barrier(0);
-    wait_vmcnt<VMCNT>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    load_frags<NTJ>(nxt, nxt_sub_patch, nxt_wt, wrow, p_lane, kh, nxt_oy, nxt_ox);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_half<NTJ, 1>(acc, cur);
+    if constexpr (VARIANT == 1) {
+        mma_half<NTJ, 0>(acc, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vmcnt<VMCNT>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        load_frags<NTJ>(nxt, nxt_sub_patch, nxt_wt, wrow, p_lane, kh, nxt_oy, nxt_ox);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half<NTJ, 1>(acc, cur);
+    } else {
+        load_frags<NTJ>(cur, cur_sub_patch, cur_wt, wrow, p_lane, kh, cur_oy, cur_ox);
+#pragma unroll
+        for (int j = 0; j < NTJ; j++) {
+            acc[0][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.wf[j], cur.pf[0], acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.wf[j], cur.pf[1], acc[1][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 + NTJ, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NTJ, 0);
+        wait_vmcnt<VMCNT>();
+        block_barrier();
+    }
 }
 
 // bias is already in the accumulator: truncate mod 256, relu7, 16 consecutive channels per lane
@@ -179,12 +196,14 @@ __host__ __device__ constexpr int has_refresh(int t) { return refresh_plane((t +
 
 // Conv: 50 steps = two channel groups (q0, q0+1) per expansion, so that the fragment set of a step
 // is a compile-time function (T & 1) of its index.
-template <int NTJ, int T>
+template <int NTJ, int VARIANT, int T>
 __device__ __forceinline__ void conv_steps(const StepCtx<NTJ> &c, const uint32_t (&poff)[4][3], int q0, uint32_t qstride)
 {
     constexpr int TB = NTJ * 32 * KSTEP, WR = (TB / 1024 + 3) / 4;
     constexpr int TT = T % 25;                      // tap index inside the channel group
-    constexpr Tap nxt = conv_tap((T + 1) % 25);     // the step whose fragments are fetched here
+    constexpr Tap tap = conv_tap(TT);
+    constexpr int plane = (tap.ky & 1) * 2 + (tap.kx & 1);
+    constexpr Tap nxt = conv_tap((T + 1) % 25);     // the step whose fragments the pipelined variant fetches
     constexpr int nxt_plane = (nxt.ky & 1) * 2 + (nxt.kx & 1);
     const int q = q0 + T / 25;
     const int step = q * 25 + TT;
@@ -201,13 +220,14 @@ __device__ __forceinline__ void conv_steps(const StepCtx<NTJ> &c, const uint32_t
     load_wtile<TB>(c.ring, c.wstream, step + PF, c.lane, c.w);
     // (3) MFMAs of this step around the barrier that publishes weight tile step+1 (issued 2 steps
     //     ago, before that step's B pieces) and every patch piece issued before it
-    pipelined_step<NTJ, (PF - 1) * WR + has_refresh(TT - 1) + has_refresh(TT)>(
-        c.acc, c.fr[T & 1], c.fr[(T + 1) & 1], c.patch + nxt_plane * SUB_ALLOC, c.ring + ((step + 1) % RING) * TB,
-        c.wrow, c.p_lane, c.kh, nxt.ky >> 1, nxt.kx >> 1);
-    if constexpr (T + 1 < 50) conv_steps<NTJ, T + 1>(c, poff, q0, qstride);
+    k_step<NTJ, (PF - 1) * WR + has_refresh(TT - 1) + has_refresh(TT), VARIANT>(
+        c.acc, c.fr[T & 1], c.fr[(T + 1) & 1], c.patch + plane * SUB_ALLOC, c.ring + (step % RING) * TB, tap.ky >> 1,
+        tap.kx >> 1, c.patch + nxt_plane * SUB_ALLOC, c.ring + ((step + 1) % RING) * TB, nxt.ky >> 1, nxt.kx >> 1,
+        c.wrow, c.p_lane, c.kh);
+    if constexpr (T + 1 < 50) conv_steps<NTJ, VARIANT, T + 1>(c, poff, q0, qstride);
 }
 
-template <int NQ, int NTJ, bool DECONV, int MINW>
+template <int NQ, int NTJ, bool DECONV, int MINW, int VARIANT>
 __global__ __launch_bounds__(256, MINW) void k_mfma_t(
     const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int8_t *__restrict__ wstream,
     const int8_t *__restrict__ bias, int IW, int IH, int OW, int OH, int MW, int MH, int tiles_x, int in_grouped,
@@ -255,7 +275,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_t(
         for (int s = 0; s < PF; s++) load_wtile<TB>(ring, wstream, s, lane, w);
         wait_vmcnt<0>();
         block_barrier();
-        load_frags<NTJ>(fr[0], patch, ring, wrow, p_lane, kh, 0, 0);  // step 0: phase (0,0), tap (0,0), group 0
+        if constexpr (VARIANT == 1) load_frags<NTJ>(fr[0], patch, ring, wrow, p_lane, kh, 0, 0);  // step 0
 
         constexpr int WR = (TB / 1024 + 3) / 4;
         int step = 0;
@@ -282,10 +302,11 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_t(
                 for (int q = 0; q < NQ; q++) {
                     load_wtile<TB>(ring, wstream, step + q + PF, lane, w);
                     const bool last = (q == NQ - 1);
-                    pipelined_step<NTJ, (PF - 1) * WR>(acc, fr[q & 1], fr[(q + 1) & 1],
-                                                       patch + (last ? 0 : q + 1) * SUB_ALLOC,
-                                                       ring + ((step + q + 1) % RING) * TB, wrow, p_lane, kh,
-                                                       last ? noy : iy + py, last ? nox : ix + px);
+                    k_step<NTJ, (PF - 1) * WR, VARIANT>(acc, fr[q & 1], fr[(q + 1) & 1], patch + q * SUB_ALLOC,
+                                                        ring + ((step + q) % RING) * TB, iy + py, ix + px,
+                                                        patch + (last ? 0 : q + 1) * SUB_ALLOC,
+                                                        ring + ((step + q + 1) % RING) * TB, last ? noy : iy + py,
+                                                        last ? nox : ix + px, wrow, p_lane, kh);
                 }
                 step += NQ;
             }
@@ -313,11 +334,11 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_t(
         for (int s = 0; s < PF; s++) load_wtile<TB>(ring, wstream, s, lane, w);
         wait_vmcnt<0>();
         block_barrier();
-        load_frags<NTJ>(fr[0], patch, ring, wrow, p_lane, kh, 0, 0);  // step 0: tap (0,0) of plane 0
+        if constexpr (VARIANT == 1) load_frags<NTJ>(fr[0], patch, ring, wrow, p_lane, kh, 0, 0);  // step 0
 
         init_acc<NTJ>(acc, bias, kh);
 #pragma unroll 1
-        for (int q0 = 0; q0 < NQ; q0 += 2) conv_steps<NTJ, 0>(ctx, poff, q0, qstride);
+        for (int q0 = 0; q0 < NQ; q0 += 2) conv_steps<NTJ, VARIANT, 0>(ctx, poff, q0, qstride);
         wait_vmcnt<0>();
         store_tiles<NTJ>(acc, out_img, OW, OH, MW, MH, Y0, X0, w, m, kh, false, 0, 0, out_grouped != 0);
     }
@@ -325,18 +346,28 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_t(
 
 // Explicit instantiations: the host stubs of a __global__ template that is only named inside
 // another template are not emitted by hipcc (ROCm 7.2) otherwise.
-#define SICN_INST(NQ, NTJ, D)                                                                               \
-    template __global__ void k_mfma_t<NQ, NTJ, D, ((NTJ <= 4 && NQ <= 4) ? 2 : 1)>(                                      \
-        const uint8_t *__restrict__, uint8_t *__restrict__, const int8_t *__restrict__,                     \
+#define SICN_INST(NQ, NTJ, D, V)                                                                            \
+    template __global__ void k_mfma_t<NQ, NTJ, D, ((NTJ <= 4 && NQ <= 4) ? 2 : 1), V>(                       \
+        const uint8_t *__restrict__, uint8_t *__restrict__, const int8_t *__restrict__,                      \
         const int8_t *__restrict__, int, int, int, int, int, int, int, int, int);
-SICN_INST(4, 4, true)
-SICN_INST(6, 4, true)
-SICN_INST(4, 4, false)
-SICN_INST(4, 6, false)
+SICN_INST(4, 4, true, 0)
+SICN_INST(4, 4, true, 1)
+SICN_INST(6, 4, true, 0)
+SICN_INST(6, 4, true, 1)
+SICN_INST(4, 4, false, 0)
+SICN_INST(4, 4, false, 1)
+SICN_INST(4, 6, false, 0)
+SICN_INST(4, 6, false, 1)
 #undef SICN_INST
 
-template <int NQ, int NTJ, bool DECONV>
-static hipError_t launch_one(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
+static int mfma_variant()
+{
+    const char *x = getenv("SICN_MFMA_VARIANT");  // read per launch: in-process A/B (tools/ab_variants.py)
+    return x ? atoi(x) : 0;
+}
+
+template <int NQ, int NTJ, bool DECONV, int VARIANT>
+static hipError_t launch_var(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
                              int n_images, hipStream_t stream, int in_grouped, int out_grouped)
 {
     constexpr int NSUB = DECONV ? NQ : 4;
@@ -345,13 +376,21 @@ static hipError_t launch_one(const LayerGeom &g, const sicn_weights &w, const ui
     const int tiles_x = (MW + TILE_X - 1) / TILE_X, tiles_y = (MH + TILE_Y - 1) / TILE_Y;
     size_t lds = (size_t)NSUB * SUB_ALLOC + (size_t)RING * NTJ * 32 * KSTEP;
     if (const char *x = getenv("SICN_DEBUG_EXTRA_LDS")) lds += (size_t)atoi(x);  // occupancy experiments only
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mfma_t<NQ, NTJ, DECONV, MINW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mfma_t<NQ, NTJ, DECONV, MINW, VARIANT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)(tiles_x * tiles_y), 1, (unsigned)n_images);
-    hipLaunchKernelGGL((k_mfma_t<NQ, NTJ, DECONV, MINW>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma,
+    hipLaunchKernelGGL((k_mfma_t<NQ, NTJ, DECONV, MINW, VARIANT>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma,
                        w.d_bias, g.IW, g.IH, g.OW, g.OH, MW, MH, tiles_x, in_grouped, out_grouped);
     return hipGetLastError();
+}
+
+template <int NQ, int NTJ, bool DECONV>
+static hipError_t launch_one(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
+                             int n_images, hipStream_t stream, int in_grouped, int out_grouped)
+{
+    return mfma_variant() == 1 ? launch_var<NQ, NTJ, DECONV, 1>(g, w, in, out, n_images, stream, in_grouped, out_grouped)
+                               : launch_var<NQ, NTJ, DECONV, 0>(g, w, in, out, n_images, stream, in_grouped, out_grouped);
 }
 
 bool mfma_supported(int cin, int cout, int transposed)
