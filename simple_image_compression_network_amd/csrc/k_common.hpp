@@ -16,8 +16,14 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int SUB_BYTES = PATCH_PIX * KSTEP;  // 10880
 constexpr int SUB_PIECES = 12;
 constexpr int SUB_ALLOC = SUB_PIECES * 1024;  // 12288
-constexpr int RING = 4;                       // weight-tile ring slots
-constexpr int PF = 3;                         // weight tiles in flight ahead of the consumer
+#ifndef SICN_RING
+#define SICN_RING 4
+#endif
+#ifndef SICN_PF
+#define SICN_PF 3
+#endif
+constexpr int RING = SICN_RING;               // weight-tile ring slots
+constexpr int PF = SICN_PF;                   // weight tiles in flight ahead of the consumer
 constexpr uint32_t OOB = 0x80000000u;         // beyond any image: the buffer range check returns 0
 
 template <int N>
@@ -50,32 +56,40 @@ __device__ __forceinline__ uint32_t pack4_relu7(int a, int b, int c, int d)
     return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, mcd), __builtin_bit_cast(uint32_t, mab), 0x07050301u);
 }
 
-// Tensor layouts.  NHWC  : [H][W][C]           (the ABI layout = the reference's stream bytes)
-//                  GROUP : [C/32][H][W][32]     (internal, between two layers of a chain: every
-//                          32-channel group is its own plane, so a kernel that walks K group by
-//                          group touches each 128-byte line once, and a lane-per-pixel epilogue
-//                          stores 1 KiB contiguous per wave instruction)
-// Byte offset of (pixel index pix, channel group g) and the stride between groups of one pixel:
-__device__ __forceinline__ uint32_t pix_group_offset(bool grouped, uint32_t pix, uint32_t g, uint32_t C,
-                                                     uint32_t plane_pixels)
+// Tensor layouts.
+//   LAYOUT_NHWC  : [H][W][C]                 the ABI layout = the reference's stream bytes
+//   LAYOUT_GROUP : [C/32][H][W][32]          internal, between two layers of a chain: every 32-channel
+//                  group is its own plane, so a kernel that walks K group by group touches each
+//                  128-byte line once and a lane-per-pixel epilogue stores 1 KiB per wave instruction
+//   LAYOUT_PHASE : [y&1][x&1][C/32][H/2][W/2][32]   GROUP split by pixel parity: what a deconv
+//                  phase (py,px) produces is then CONTIGUOUS (its outputs are the pixels of one
+//                  parity), instead of 32-byte pieces at a 64-byte stride
+constexpr int LAYOUT_NHWC = 0, LAYOUT_GROUP = 1, LAYOUT_PHASE = 2;
+
+// byte offset of channel group g of pixel (y, x) in an image of W x H pixels, C channels
+__device__ __forceinline__ uint32_t tensor_offset(int layout, int y, int x, uint32_t g, int C, int W, int H)
 {
-    return grouped ? (g * plane_pixels + pix) * 32u : pix * C + g * 32u;
+    if (layout == LAYOUT_NHWC) return (uint32_t)(y * W + x) * (uint32_t)C + g * 32u;
+    if (layout == LAYOUT_GROUP) return (g * (uint32_t)(W * H) + (uint32_t)(y * W + x)) * 32u;
+    const uint32_t hw = (uint32_t)((W >> 1) * (H >> 1));
+    const uint32_t plane = (uint32_t)((y & 1) * 2 + (x & 1)) * (uint32_t)(C >> 5) + g;
+    return (plane * hw + (uint32_t)((y >> 1) * (W >> 1) + (x >> 1))) * 32u;
 }
 
 // Source offset (bytes from the image base) of this lane's 16 bytes of LDS-DMA piece `k` of a
 // sub-patch: position p = k*32 + lane/2 of the (TILE_Y+2) x (TILE_X+2) window whose origin is
 // (Yb, Xb) in "patch coordinates"; patch coordinate (ty,tx) maps to input pixel
-// (sy*(Yb+ty)+ay, sx*(Xb+tx)+ax).  The LDS image keeps logical half h of position p at physical
-// half h ^ ((p>>3)&1) (bank-conflict-free ds_read_b128, see DESIGN.md §3.3).
+// (s*(Yb+ty)+ay, s*(Xb+tx)+ax).  The LDS image keeps logical half h of position p at physical
+// half h ^ ((p>>3)&1) (bank-conflict-free ds_read_b128, see DESIGN.md §3.1).
 __device__ __forceinline__ uint32_t piece_src_offset(int k, int lane, int Yb, int Xb, int s, int ay, int ax,
-                                                     int IW, int IH, bool grouped, uint32_t g, uint32_t C)
+                                                     int IW, int IH, int layout, uint32_t g, int C)
 {
     const int p = k * 32 + (lane >> 1);
     const int ty = p / PATCH_X, tx = p - ty * PATCH_X;
     const int hlog = (lane & 1) ^ ((p >> 3) & 1);
     const int iy = s * (Yb + ty) + ay, ix = s * (Xb + tx) + ax;
     const bool ok = p < PATCH_PIX && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
-    return ok ? pix_group_offset(grouped, (uint32_t)(iy * IW + ix), g, C, (uint32_t)(IW * IH)) + hlog * 16 : OOB;
+    return ok ? tensor_offset(layout, iy, ix, g, C, IW, IH) + hlog * 16 : OOB;
 }
 
 // one LDS-DMA piece (1 KiB) of sub-patch `sub`

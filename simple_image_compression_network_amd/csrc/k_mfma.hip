@@ -113,16 +113,25 @@ __device__ __forceinline__ void mma_half(v16i (&acc)[2][NTJ], const Frags<NTJ> &
 // VARIANT 0 (simple)   : ds_read fragments of step s | all MFMAs | vmcnt + barrier.
 // Both are kept for in-process A/B runs (SICN_MFMA_VARIANT): on a power-limited chip the simpler
 // stream is not necessarily the slower one.
-template <int NTJ, int VMCNT, int VARIANT>
+template <int VMCNT, int EXTRA>
+__device__ __forceinline__ void wait_tiles(bool extra)
+{
+    if (EXTRA > 0 && extra)
+        wait_vmcnt<VMCNT + EXTRA>();
+    else
+        wait_vmcnt<VMCNT>();
+}
+
+template <int NTJ, int VMCNT, int VARIANT, int EXTRA = 0>
 __device__ __forceinline__ void k_step(v16i (&acc)[2][NTJ], Frags<NTJ> &cur, Frags<NTJ> &nxt,
                                        const uint8_t *cur_sub_patch, const uint8_t *cur_wt, int cur_oy, int cur_ox,
                                        const uint8_t *nxt_sub_patch, const uint8_t *nxt_wt, int nxt_oy, int nxt_ox,
-                                       const uint32_t (&wrow)[NTJ], int p_lane, int kh)
+                                       const uint32_t (&wrow)[NTJ], int p_lane, int kh, bool extra = false)
 {
     if constexpr (VARIANT == 1) {
         mma_half<NTJ, 0>(acc, cur);
         __builtin_amdgcn_sched_barrier(0);
-        wait_vmcnt<VMCNT>();
+        wait_tiles<VMCNT, EXTRA>(extra);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         load_frags<NTJ>(nxt, nxt_sub_patch, nxt_wt, wrow, p_lane, kh, nxt_oy, nxt_ox);
@@ -137,7 +146,7 @@ __device__ __forceinline__ void k_step(v16i (&acc)[2][NTJ], Frags<NTJ> &cur, Fra
         }
         __builtin_amdgcn_sched_group_barrier(0x100, 2 + NTJ, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * NTJ, 0);
-        wait_vmcnt<VMCNT>();
+        wait_tiles<VMCNT, EXTRA>(extra);
         block_barrier();
     }
 }
@@ -146,15 +155,14 @@ __device__ __forceinline__ void k_step(v16i (&acc)[2][NTJ], Frags<NTJ> &cur, Fra
 template <int NTJ>
 __device__ __forceinline__ void store_tiles(const v16i (&acc)[2][NTJ], uint8_t *out_img, int OW, int OH, int MW,
                                             int MH, int Y0, int X0, int w, int m, int kh, bool deconv, int py,
-                                            int px, bool out_grouped)
+                                            int px, int out_layout, int dbg = 0)
 {
     constexpr int COUT = NTJ * 32;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         const int gy = Y0 + 2 * w + i, gx = X0 + m;
-        if (gy < MH && gx < MW) {
+        if (gy < MH && gx < MW && !(dbg & 1)) {
             const int oy_ = deconv ? 2 * gy + py : gy, ox_ = deconv ? 2 * gx + px : gx;
-            const size_t pix = (size_t)oy_ * OW + ox_;
 #pragma unroll
             for (int j = 0; j < NTJ; j++) {
                 const v16i a = acc[i][j];
@@ -163,9 +171,7 @@ __device__ __forceinline__ void store_tiles(const v16i (&acc)[2][NTJ], uint8_t *
                 v.y = pack4_relu7(a[4], a[5], a[6], a[7]);
                 v.z = pack4_relu7(a[8], a[9], a[10], a[11]);
                 v.w = pack4_relu7(a[12], a[13], a[14], a[15]);
-                uint8_t *dst = out_grouped ? out_img + ((size_t)j * OW * OH + pix) * 32 + 16 * kh
-                                           : out_img + pix * COUT + j * 32 + 16 * kh;
-                *(uint4 *)dst = v;
+                *(uint4 *)(out_img + tensor_offset(out_layout, oy_, ox_, (uint32_t)j, COUT, OW, OH) + 16 * kh) = v;
             }
         }
     }
@@ -192,7 +198,15 @@ __host__ __device__ constexpr int refresh_plane(int t)
     return (t >= 0 && t < 3) ? 3 : (t >= 9 && t < 12) ? 0 : (t >= 15 && t < 18) ? 1 : (t >= 21 && t < 24) ? 2 : -1;
 }
 __host__ __device__ constexpr int refresh_slot(int t) { return t < 3 ? t : t < 12 ? t - 9 : t < 18 ? t - 15 : t - 21; }
-__host__ __device__ constexpr int has_refresh(int t) { return refresh_plane((t + 25) % 25) >= 0 ? 1 : 0; }
+__host__ __device__ constexpr int has_refresh(int t) { return refresh_plane((t + 50) % 25) >= 0 ? 1 : 0; }
+// patch pieces issued in the PF-1 steps up to and including step t (they are younger than the
+// weight tile the step waits for)
+__host__ __device__ constexpr int refresh_count(int t)
+{
+    int n = 0;
+    for (int k = 0; k < PF - 1; k++) n += has_refresh(t - k);
+    return n;
+}
 
 // Conv: 50 steps = two channel groups (q0, q0+1) per expansion, so that the fragment set of a step
 // is a compile-time function (T & 1) of its index.
@@ -220,7 +234,7 @@ __device__ __forceinline__ void conv_steps(const StepCtx<NTJ> &c, const uint32_t
     load_wtile<TB>(c.ring, c.wstream, step + PF, c.lane, c.w);
     // (3) MFMAs of this step around the barrier that publishes weight tile step+1 (issued 2 steps
     //     ago, before that step's B pieces) and every patch piece issued before it
-    k_step<NTJ, (PF - 1) * WR + has_refresh(TT - 1) + has_refresh(TT), VARIANT>(
+    k_step<NTJ, (PF - 1) * WR + refresh_count(TT), VARIANT>(
         c.acc, c.fr[T & 1], c.fr[(T + 1) & 1], c.patch + plane * SUB_ALLOC, c.ring + (step % RING) * TB, tap.ky >> 1,
         tap.kx >> 1, c.patch + nxt_plane * SUB_ALLOC, c.ring + ((step + 1) % RING) * TB, nxt.ky >> 1, nxt.kx >> 1,
         c.wrow, c.p_lane, c.kh);
@@ -230,8 +244,8 @@ __device__ __forceinline__ void conv_steps(const StepCtx<NTJ> &c, const uint32_t
 template <int NQ, int NTJ, bool DECONV, int MINW, int VARIANT>
 __global__ __launch_bounds__(256, MINW) void k_mfma_t(
     const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int8_t *__restrict__ wstream,
-    const int8_t *__restrict__ bias, int IW, int IH, int OW, int OH, int MW, int MH, int tiles_x, int in_grouped,
-    int out_grouped)
+    const int8_t *__restrict__ bias, int IW, int IH, int OW, int OH, int MW, int MH, int tiles_x, int in_layout,
+    int out_layout, int dbg)
 {
     constexpr int CIN = NQ * 32, COUT = NTJ * 32;
     constexpr int NSUB = DECONV ? NQ : 4;
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_t(
 #pragma unroll
             for (int slot = 0; slot < 3; slot++)
                 load_piece(patch, in_img, in_img_bytes, sub, slot * 4 + w,
-                           piece_src_offset(slot * 4 + w, lane, Y0 - 1, X0 - 1, 1, 0, 0, IW, IH, in_grouped != 0,
+                           piece_src_offset(slot * 4 + w, lane, Y0 - 1, X0 - 1, 1, 0, 0, IW, IH, in_layout,
                                             (uint32_t)sub, CIN));
 #pragma unroll
         for (int s = 0; s < PF; s++) load_wtile<TB>(ring, wstream, s, lane, w);
@@ -302,16 +316,19 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_t(
                 for (int q = 0; q < NQ; q++) {
                     load_wtile<TB>(ring, wstream, step + q + PF, lane, w);
                     const bool last = (q == NQ - 1);
-                    k_step<NTJ, (PF - 1) * WR, VARIANT>(acc, fr[q & 1], fr[(q + 1) & 1], patch + q * SUB_ALLOC,
-                                                        ring + ((step + q) % RING) * TB, iy + py, ix + px,
-                                                        patch + (last ? 0 : q + 1) * SUB_ALLOC,
-                                                        ring + ((step + q + 1) % RING) * TB, last ? noy : iy + py,
-                                                        last ? nox : ix + px, wrow, p_lane, kh);
+                    // the 2*NTJ output stores of the previous phase sit between the awaited weight tile
+                    // and this step for the first PF-1 steps of a phase: count them, do not wait for them
+                    k_step<NTJ, (PF - 1) * WR, VARIANT, 2 * NTJ>(acc, fr[q & 1], fr[(q + 1) & 1], patch + q * SUB_ALLOC,
+                                                                 ring + ((step + q) % RING) * TB, iy + py, ix + px,
+                                                                 patch + (last ? 0 : q + 1) * SUB_ALLOC,
+                                                                 ring + ((step + q + 1) % RING) * TB, last ? noy : iy + py,
+                                                                 last ? nox : ix + px, wrow, p_lane, kh,
+                                                                 ph > 0 && t == 0 && q < PF - 1);
                 }
                 step += NQ;
             }
             if (ph == 3) wait_vmcnt<0>();  // the padded tail of the weight prefetch must land before exit
-            store_tiles<NTJ>(acc, out_img, OW, OH, MW, MH, Y0, X0, w, m, kh, true, py, px, out_grouped != 0);
+            store_tiles<NTJ>(acc, out_img, OW, OH, MW, MH, Y0, X0, w, m, kh, true, py, px, out_layout, dbg);
         }
     } else {
         static_assert(DECONV || NQ % 2 == 0, "conv walks channel groups in pairs");
@@ -322,8 +339,8 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_t(
 #pragma unroll
             for (int slot = 0; slot < 3; slot++)
                 poff[pl][slot] = piece_src_offset(slot * 4 + w, lane, Y0 - 1, X0 - 1, 2, pl >> 1, pl & 1, IW, IH,
-                                                  in_grouped != 0, 0u, CIN);
-        const uint32_t qstride = in_grouped ? (uint32_t)(IW * IH * 32) : 32u;
+                                                  in_layout, 0u, CIN);
+        const uint32_t qstride = in_layout == LAYOUT_GROUP ? (uint32_t)(IW * IH * 32) : 32u;  // conv: NHWC or GROUP
         // ---- prologue: planes 0..2 of group 0 (plane 3 arrives in steps 0..2) + PF weight tiles --
 #pragma unroll
         for (int pl = 0; pl < 3; pl++)
@@ -340,7 +357,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_t(
 #pragma unroll 1
         for (int q0 = 0; q0 < NQ; q0 += 2) conv_steps<NTJ, VARIANT, 0>(ctx, poff, q0, qstride);
         wait_vmcnt<0>();
-        store_tiles<NTJ>(acc, out_img, OW, OH, MW, MH, Y0, X0, w, m, kh, false, 0, 0, out_grouped != 0);
+        store_tiles<NTJ>(acc, out_img, OW, OH, MW, MH, Y0, X0, w, m, kh, false, 0, 0, out_layout, dbg);
     }
 }
 
@@ -349,7 +366,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_t(
 #define SICN_INST(NQ, NTJ, D, V)                                                                            \
     template __global__ void k_mfma_t<NQ, NTJ, D, ((NTJ <= 4 && NQ <= 4) ? 2 : 1), V>(                       \
         const uint8_t *__restrict__, uint8_t *__restrict__, const int8_t *__restrict__,                      \
-        const int8_t *__restrict__, int, int, int, int, int, int, int, int, int);
+        const int8_t *__restrict__, int, int, int, int, int, int, int, int, int, int);
 SICN_INST(4, 4, true, 0)
 SICN_INST(4, 4, true, 1)
 SICN_INST(6, 4, true, 0)
@@ -368,7 +385,7 @@ static int mfma_variant()
 
 template <int NQ, int NTJ, bool DECONV, int VARIANT>
 static hipError_t launch_var(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                             int n_images, hipStream_t stream, int in_grouped, int out_grouped)
+                             int n_images, hipStream_t stream, int in_layout, int out_layout)
 {
     constexpr int NSUB = DECONV ? NQ : 4;
     constexpr int MINW = ((NTJ <= 4 && NQ <= 4) ? 2 : 1);
@@ -381,16 +398,17 @@ static hipError_t launch_var(const LayerGeom &g, const sicn_weights &w, const ui
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)(tiles_x * tiles_y), 1, (unsigned)n_images);
     hipLaunchKernelGGL((k_mfma_t<NQ, NTJ, DECONV, MINW, VARIANT>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma,
-                       w.d_bias, g.IW, g.IH, g.OW, g.OH, MW, MH, tiles_x, in_grouped, out_grouped);
+                       w.d_bias, g.IW, g.IH, g.OW, g.OH, MW, MH, tiles_x, in_layout, out_layout,
+                       getenv("SICN_DEBUG_KERNEL") ? atoi(getenv("SICN_DEBUG_KERNEL")) : 0);
     return hipGetLastError();
 }
 
 template <int NQ, int NTJ, bool DECONV>
 static hipError_t launch_one(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                             int n_images, hipStream_t stream, int in_grouped, int out_grouped)
+                             int n_images, hipStream_t stream, int in_layout, int out_layout)
 {
-    return mfma_variant() == 1 ? launch_var<NQ, NTJ, DECONV, 1>(g, w, in, out, n_images, stream, in_grouped, out_grouped)
-                               : launch_var<NQ, NTJ, DECONV, 0>(g, w, in, out, n_images, stream, in_grouped, out_grouped);
+    return mfma_variant() == 1 ? launch_var<NQ, NTJ, DECONV, 1>(g, w, in, out, n_images, stream, in_layout, out_layout)
+                               : launch_var<NQ, NTJ, DECONV, 0>(g, w, in, out, n_images, stream, in_layout, out_layout);
 }
 
 bool mfma_supported(int cin, int cout, int transposed)
@@ -400,15 +418,15 @@ bool mfma_supported(int cin, int cout, int transposed)
 }
 
 hipError_t launch_mfma(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                       int n_images, hipStream_t stream, int in_grouped, int out_grouped)
+                       int n_images, hipStream_t stream, int in_layout, int out_layout)
 {
     if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB) return hipErrorInvalidValue;
     if (g.transposed) {
-        if (g.CIN == 128 && g.COUT == 128) return launch_one<4, 4, true>(g, w, in, out, n_images, stream, in_grouped, out_grouped);
-        if (g.CIN == 192 && g.COUT == 128) return launch_one<6, 4, true>(g, w, in, out, n_images, stream, in_grouped, out_grouped);
+        if (g.CIN == 128 && g.COUT == 128) return launch_one<4, 4, true>(g, w, in, out, n_images, stream, in_layout, out_layout);
+        if (g.CIN == 192 && g.COUT == 128) return launch_one<6, 4, true>(g, w, in, out, n_images, stream, in_layout, out_layout);
     } else {
-        if (g.CIN == 128 && g.COUT == 128) return launch_one<4, 4, false>(g, w, in, out, n_images, stream, in_grouped, out_grouped);
-        if (g.CIN == 128 && g.COUT == 192) return launch_one<4, 6, false>(g, w, in, out, n_images, stream, in_grouped, out_grouped);
+        if (g.CIN == 128 && g.COUT == 128) return launch_one<4, 4, false>(g, w, in, out, n_images, stream, in_layout, out_layout);
+        if (g.CIN == 128 && g.COUT == 192) return launch_one<4, 6, false>(g, w, in, out, n_images, stream, in_layout, out_layout);
     }
     return hipErrorInvalidValue;
 }

@@ -77,7 +77,7 @@ template <int NTJ>
 __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                const int8_t *__restrict__ w_l0,
                                                const int8_t *__restrict__ bias, int IW, int IH, int OW,
-                                               int OH, int tiles_y, int y_chunks, int out_grouped)
+                                               int OH, int tiles_y, int y_chunks, int out_layout)
 {
     constexpr int COUT = NTJ * 32;
     constexpr int TB = COUT * KSTEP;
@@ -164,7 +164,6 @@ __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, u
         for (int i = 0; i < 2; i++) {
             const int gy = Y0 + 2 * w + i, gx = X0 + m;
             if (gy < OH && gx < OW) {
-                const size_t pix = (size_t)gy * OW + gx;
 #pragma unroll
                 for (int j = 0; j < NTJ; j++) {
                     const v16i a = acc[i][j];
@@ -173,9 +172,7 @@ __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, u
                     v.y = pack4_relu7(a[4], a[5], a[6], a[7]);
                     v.z = pack4_relu7(a[8], a[9], a[10], a[11]);
                     v.w = pack4_relu7(a[12], a[13], a[14], a[15]);
-                    uint8_t *dst = out_grouped ? out_img + ((size_t)j * OW * OH + pix) * 32 + 16 * kh
-                                               : out_img + pix * COUT + j * 32 + 16 * kh;
-                    *(uint4 *)dst = v;
+                    *(uint4 *)(out_img + tensor_offset(out_layout, gy, gx, (uint32_t)j, COUT, OW, OH) + 16 * kh) = v;
                 }
             }
         }
@@ -204,7 +201,7 @@ void pack_l0(const int8_t *w_okc, int cout, int8_t *dst)
 }
 
 hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream, int out_grouped)
+                     int n_images, hipStream_t stream, int out_layout)
 {
     const int tiles_x = (g.OW + TILE_X - 1) / TILE_X, tiles_y = (g.OH + TILE_Y - 1) / TILE_Y;
     int y_chunks = (4096 + tiles_x * n_images - 1) / (tiles_x * n_images);
@@ -214,7 +211,7 @@ hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
     if (g.COUT == 128) {
         const size_t lds = 5 * 128 * KSTEP + 2 * L0_PATCH;
         hipLaunchKernelGGL(k_l0<4>, grid, dim3(256), lds, stream, in, out, w.d_w_l0, w.d_bias, g.IW, g.IH,
-                           g.OW, g.OH, tiles_y, y_chunks, out_grouped);
+                           g.OW, g.OH, tiles_y, y_chunks, out_layout);
     } else
         return hipErrorInvalidValue;
     return hipGetLastError();
@@ -240,7 +237,7 @@ constexpr int L7_STAGE = 4 * 192;                       // 4 output rows x 64 pi
 __global__ __launch_bounds__(256, 2) void k_l7(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                const int8_t *__restrict__ w_l7,
                                                const int8_t *__restrict__ bias, int IW, int IH, int OW,
-                                               int OH, int tiles_y, int y_chunks, int in_grouped)
+                                               int OH, int tiles_y, int y_chunks, int in_layout)
 {
     constexpr int CIN = 128;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -283,9 +280,7 @@ __global__ __launch_bounds__(256, 2) void k_l7(const uint8_t *__restrict__ in, u
                 const int c2 = (lane & 3) ^ ((p >> 2) & 3);     // channel group of 32 = 2*half + (kg>>1)
                 const int iy = Y0 - 1 + ty, ix = X0 - 1 + tx;
                 const bool ok = p < PATCH_PIX && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
-                const uint32_t off = ok ? pix_group_offset(in_grouped != 0, (uint32_t)(iy * IW + ix), (uint32_t)c2, CIN,
-                                                           (uint32_t)(IW * IH)) + 16u * region
-                                        : OOB;
+                const uint32_t off = ok ? tensor_offset(in_layout, iy, ix, (uint32_t)c2, CIN, IW, IH) + 16u * region : OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(patch + piece * 1024), 16, off, 0, 0, 0);
             }
         }
@@ -376,7 +371,7 @@ void pack_l7(const int8_t *w_okc, int cin, int8_t *dst)
 }
 
 hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream, int in_grouped)
+                     int n_images, hipStream_t stream, int in_layout)
 {
     if (g.CIN != 128 || g.COUT != 3) return hipErrorInvalidValue;
     if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB) return hipErrorInvalidValue;
@@ -387,7 +382,7 @@ hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
     hipError_t e = hipFuncSetAttribute((const void *)k_l7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_l7, dim3((unsigned)tiles_x, (unsigned)y_chunks, (unsigned)n_images), dim3(256), lds, stream,
-                       in, out, w.d_w_l7, w.d_bias, g.IW, g.IH, g.OW, g.OH, tiles_y, y_chunks, in_grouped);
+                       in, out, w.d_w_l7, w.d_bias, g.IW, g.IH, g.OW, g.OH, tiles_y, y_chunks, in_layout);
     return hipGetLastError();
 }
 

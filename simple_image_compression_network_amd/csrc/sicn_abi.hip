@@ -1,6 +1,7 @@
 // libsicn.so — C ABI (include/sicn.h): descriptor validation, weight ingestion from the
 // reference's FixedPointWeights tile format, kernel dispatch, layer chains with caller-provided
 // workspace, per-layer hipEvent timing.  Host code only; kernels live in k_*.hip.
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -169,20 +170,24 @@ extern "C" int sicn_weights_from_finn_tiles(const sicn_layer_desc *d, const void
 }
 
 // ---- single layers ------------------------------------------------------------------------------
-// Which sides of a layer can use the grouped layout [C/32][H][W][32] (k_common.hpp)?
-static bool can_read_grouped(const sicn_layer_desc &d)
+// Layout of the tensor between layer `p` (producer) and layer `c` (consumer) of a chain: the best
+// one both kernels implement (k_common.hpp).  0 = NHWC, 1 = GROUP, 2 = PHASE.
+static int link_layout(const sicn_layer_desc &p, const sicn_layer_desc &c)
 {
-    const KernelKind k = pick_kernel(d);
-    return k == KK_MFMA_CONV || k == KK_MFMA_DECONV || k == KK_L7_RGB;
-}
-static bool can_write_grouped(const sicn_layer_desc &d)
-{
-    const KernelKind k = pick_kernel(d);
-    return k == KK_MFMA_CONV || k == KK_MFMA_DECONV || k == KK_L0_RGB;
+    const KernelKind kp = pick_kernel(p), kc = pick_kernel(c);
+    const bool w_group = kp == KK_MFMA_CONV || kp == KK_MFMA_DECONV || kp == KK_L0_RGB;
+    const bool w_phase = kp == KK_MFMA_DECONV;   // its outputs come one pixel parity at a time
+    const bool r_group = kc == KK_MFMA_CONV || kc == KK_MFMA_DECONV || kc == KK_L7_RGB;
+    const bool r_phase = kc == KK_MFMA_DECONV || kc == KK_L7_RGB;
+    const char *np = getenv("SICN_NO_PHASE_LAYOUT");   // experiments: "1" = never, "2" = not towards the RGB layer
+    const bool phase_ok = !np || np[0] == '0' || (np[0] == '2' && kc != KK_L7_RGB);
+    if (w_phase && r_phase && phase_ok) return 2;
+    if (w_group && r_group) return 1;
+    return 0;
 }
 
 static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream, int want_transposed, int in_grouped = 0, int out_grouped = 0)
+                     int n_images, hipStream_t stream, int want_transposed, int in_layout = 0, int out_layout = 0)
 {
     int rc = sicn_validate_desc(d);
     if (rc) return rc;
@@ -194,10 +199,10 @@ static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint
     const LayerGeom g = geom_of(*d);
     hipError_t e;
     switch (pick_kernel(*d)) {
-    case KK_L0_RGB: e = launch_l0(g, *w, in, out, n_images, stream, out_grouped); break;
-    case KK_L7_RGB: e = launch_l7(g, *w, in, out, n_images, stream, in_grouped); break;
+    case KK_L0_RGB: e = launch_l0(g, *w, in, out, n_images, stream, out_layout); break;
+    case KK_L7_RGB: e = launch_l7(g, *w, in, out, n_images, stream, in_layout); break;
     case KK_MFMA_CONV:
-    case KK_MFMA_DECONV: e = launch_mfma(g, *w, in, out, n_images, stream, in_grouped, out_grouped); break;
+    case KK_MFMA_DECONV: e = launch_mfma(g, *w, in, out, n_images, stream, in_layout, out_layout); break;
     default: e = launch_generic(g, *w, in, out, n_images, stream); break;
     }
     if (e == hipErrorInvalidValue) return SICN_EINVAL;
@@ -298,16 +303,15 @@ extern "C" int sicn_net_forward(const sicn_net *net_c, int first, int last, cons
     hipStream_t stream = (hipStream_t)hip_stream;
     uint8_t *pp[2] = {(uint8_t *)workspace, (uint8_t *)workspace + slot};
     const uint8_t *cur = in;
-    int cur_grouped = 0;  // the chain's input is always NHWC
+    int cur_layout = 0;  // the chain's input is always NHWC
     for (int l = first; l <= last; l++) {
         uint8_t *dst = (l == last) ? out : pp[(l - first) & 1];
         // intermediates nobody outside sees travel in the grouped layout when both neighbours can
-        const int out_grouped = (l < last && l != tap_layer && can_write_grouped(net->descs[l]) &&
-                                 can_read_grouped(net->descs[l + 1])) ? 1 : 0;
+        const int out_layout = (l < last && l != tap_layer) ? link_layout(net->descs[l], net->descs[l + 1]) : 0;
         const bool prof = net->profile && net->ev_count[l] < sicn_net::EV_RING;
         if (prof && hipEventRecord(net->ev_begin[(size_t)l * sicn_net::EV_RING + net->ev_count[l]], stream) != hipSuccess)
             return SICN_ENODEV;
-        int rc = run_layer(&net->descs[l], net->weights[l], cur, dst, n_images, stream, -1, cur_grouped, out_grouped);
+        int rc = run_layer(&net->descs[l], net->weights[l], cur, dst, n_images, stream, -1, cur_layout, out_layout);
         if (rc) return rc;
         if (prof) {
             if (hipEventRecord(net->ev_end[(size_t)l * sicn_net::EV_RING + net->ev_count[l]], stream) != hipSuccess)
@@ -320,7 +324,7 @@ extern "C" int sicn_net_forward(const sicn_net *net_c, int first, int last, cons
                 return SICN_ENODEV;
         }
         cur = dst;
-        cur_grouped = out_grouped;
+        cur_layout = out_layout;
     }
     (void)in_bytes;
     return SICN_OK;

@@ -54,13 +54,13 @@ KernelKind pick_kernel(const sicn_layer_desc &d);
 // Launchers: enqueue on `stream`, return hipError_t of the launch.
 hipError_t launch_generic(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
                           int n_images, hipStream_t stream);
-// in_grouped / out_grouped: 0 = NHWC (the ABI layout), 1 = [C/32][H][W][32] (k_common.hpp)
+// in_layout / out_layout: LAYOUT_NHWC (the ABI layout) / LAYOUT_GROUP / LAYOUT_PHASE (k_common.hpp)
 hipError_t launch_mfma(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                       int n_images, hipStream_t stream, int in_grouped, int out_grouped);
+                       int n_images, hipStream_t stream, int in_layout, int out_layout);
 hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream, int out_grouped);
+                     int n_images, hipStream_t stream, int out_layout);
 hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream, int in_grouped);
+                     int n_images, hipStream_t stream, int in_layout);
 
 // Host-side weight packers (pure CPU, unit-testable without a GPU).
 // w_okc: [cout][25*cin].  Returns bytes written into `dst` (size from *_bytes()).
