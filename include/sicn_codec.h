@@ -1,0 +1,66 @@
+/*
+ * sicn_codec.h — latent container ("SICL" v1) and static rANS entropy coder on the GPU.
+ *
+ * EXTENSION BEYOND THE REFERENCE.  The reference never encodes its latent: `conv_3_out` is an
+ * in-memory stream handed straight to layer 4 (conv_nonsquare_top.cpp:322-332) and the tree
+ * contains no coder, CDF or bitstream of any kind.  These entry points therefore
+ * replace NO reference interface; they implement SURVEY.md §8(f) rows 1-2 to this project's own
+ * specification (oracle/sicn_codec_oracle.c states it in full).  Parity status: UNPINNED — the
+ * tests show decode(encode(x)) == x and GPU output == CPU oracle output, byte for byte.
+ *
+ * Container: 48-byte header (magic "SICL", version, mode, image and latent dimensions, stream
+ * count, payload size, adler32 of the latent), then for mode 2 a 128 x u16 frequency table and a
+ * u32 byte count per stream, then the payload.  Symbols are latent bytes, which are < 128
+ * (conv_nonsquare_top.cpp:273-275 zeroes every value with the MSB set).
+ *   mode 0  raw8     payload = the latent
+ *   mode 1  packed7  8 symbols -> 7 bytes
+ *   mode 2  rANS     byte-wise rANS, 12-bit static frequencies measured on this latent, independent
+ *                    streams of 1024 symbols (one GPU lane per stream), stream offsets by a
+ *                    wavefront-level prefix scan
+ *
+ * All pointers are DEVICE pointers unless named *_host.  Unlike sicn.h's launch functions, these
+ * calls synchronise `hip_stream` (sizes have to come back to the caller).
+ */
+#ifndef SICN_CODEC_H
+#define SICN_CODEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SICN_CODEC_RAW8 0
+#define SICN_CODEC_PACKED7 1
+#define SICN_CODEC_RANS 2
+#define SICN_CODEC_HEADER_BYTES 48
+#define SICN_CODEC_STREAM_SYMBOLS 1024
+#define SICN_EBADMSG (-74) /* checksum of the decoded latent does not match the header */
+
+typedef struct sicn_codec_info {
+    uint32_t mode, image_width, image_height, lat_w, lat_h, lat_c, n_symbols, n_streams, payload_bytes, adler32;
+} sicn_codec_info;
+
+/* Upper bound of the container size / device scratch needed for n_symbols latent bytes. */
+size_t sicn_codec_max_bytes(int mode, uint32_t n_symbols);
+size_t sicn_codec_workspace_bytes(int mode, uint32_t n_symbols);
+
+/* latent: [lat_h][lat_w][lat_c] uint8 (values < 128, else SICN_EINVAL).  Writes the container to
+ * `out` (capacity >= sicn_codec_max_bytes) and its size to *out_bytes. */
+int sicn_codec_encode(int mode, const uint8_t *latent, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c,
+                      uint32_t image_width, uint32_t image_height, uint8_t *out, size_t out_capacity,
+                      size_t *out_bytes, void *workspace, size_t workspace_bytes, void *hip_stream);
+
+/* Parses a container header from HOST memory (first SICN_CODEC_HEADER_BYTES bytes). */
+int sicn_codec_parse_header(const uint8_t *header_host, size_t bytes, sicn_codec_info *info);
+
+/* Decodes a container held in device memory into `latent` (capacity >= n_symbols) and verifies the
+ * checksum (SICN_EBADMSG on mismatch, SICN_EINVAL on a malformed container). */
+int sicn_codec_decode(const uint8_t *container, size_t bytes, uint8_t *latent, size_t latent_capacity,
+                      sicn_codec_info *info_or_null, void *workspace, size_t workspace_bytes, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SICN_CODEC_H */

@@ -45,8 +45,46 @@ def lib() -> ctypes.CDLL:
         L.sicn_or_swg_nonsquare_fsm.restype = ctypes.c_longlong
         L.sicn_or_im2col_s1.argtypes = [p, p] + [ctypes.c_int] * 5
         L.sicn_or_im2col_s1.restype = None
+        L.sicl_or_max_bytes.argtypes = [ctypes.c_int, ctypes.c_uint32]
+        L.sicl_or_max_bytes.restype = ctypes.c_size_t
+        L.sicl_or_encode.argtypes = [ctypes.c_int, p] + [ctypes.c_uint32] * 5 + [p, ctypes.c_size_t]
+        L.sicl_or_encode.restype = ctypes.c_longlong
+        L.sicl_or_decode.argtypes = [p, ctypes.c_size_t, p, ctypes.c_size_t, p]
+        L.sicl_or_decode.restype = ctypes.c_longlong
+        L.sicl_or_normalize.argtypes = [p, ctypes.c_uint32, p]
+        L.sicl_or_normalize.restype = ctypes.c_int
+        L.sicl_or_adler32.argtypes = [p, ctypes.c_size_t]
+        L.sicl_or_adler32.restype = ctypes.c_uint32
         _LIB = L
     return _LIB
+
+
+def codec_encode(latent: np.ndarray, image_wh=(0, 0), mode: int = 2) -> bytes:
+    """Oracle statement of the "SICL" container (sicn_codec_oracle.c). latent: [h][w][c] uint8."""
+    latent = np.ascontiguousarray(latent, dtype=np.uint8)
+    h, w, c = latent.shape
+    L = lib()
+    cap = L.sicl_or_max_bytes(mode, latent.size)
+    out = np.zeros(max(cap, 64), np.uint8)
+    n = L.sicl_or_encode(mode, _ptr(latent), w, h, c, image_wh[0], image_wh[1], _ptr(out), out.size)
+    if n < 0:
+        raise RuntimeError(f"sicl_or_encode rc={n}")
+    return out[:n].tobytes()
+
+
+def codec_decode(container: bytes):
+    """Returns (latent [h][w][c], info[8] = mode, img_w, img_h, lat_w, lat_h, lat_c, n, payload)."""
+    buf = np.frombuffer(container, np.uint8).copy()
+    info = np.zeros(8, np.uint32)
+    L = lib()
+    probe = L.sicl_or_decode(_ptr(buf), buf.size, None, 0, _ptr(info))
+    if probe not in (-28, 0):
+        raise RuntimeError(f"sicl_or_decode rc={probe}")
+    lat = np.zeros(max(int(info[6]), 1), np.uint8)
+    n = L.sicl_or_decode(_ptr(buf), buf.size, _ptr(lat), lat.size, _ptr(info))
+    if n < 0:
+        raise RuntimeError(f"sicl_or_decode rc={n}")
+    return lat[: int(info[6])].reshape(int(info[4]), int(info[3]), int(info[5])), info
 
 
 def _desc(d) -> OrDesc:

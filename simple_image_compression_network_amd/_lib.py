@@ -35,6 +35,23 @@ ABI = {
     "sicn_net_layer_ms": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]),
 }
 
+
+class CodecInfo(ctypes.Structure):
+    """ctypes image of `sicn_codec_info` (include/sicn_codec.h)."""
+    _fields_ = [(n, ctypes.c_uint32) for n in ("mode", "image_width", "image_height", "lat_w", "lat_h", "lat_c",
+                                               "n_symbols", "n_streams", "payload_bytes", "adler32")]
+
+
+_u32 = ctypes.c_uint32
+# include/sicn_codec.h (extension beyond the reference: latent container + rANS coder)
+CODEC_ABI = {
+    "sicn_codec_max_bytes": (_sz, [_i, _u32]),
+    "sicn_codec_workspace_bytes": (_sz, [_i, _u32]),
+    "sicn_codec_encode": (_i, [_i, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _sz, ctypes.POINTER(_sz), _vp, _sz, _vp]),
+    "sicn_codec_parse_header": (_i, [_vp, _sz, ctypes.POINTER(CodecInfo)]),
+    "sicn_codec_decode": (_i, [_vp, _sz, _vp, _sz, ctypes.POINTER(CodecInfo), _vp, _sz, _vp]),
+}
+
 _lib = None
 
 
@@ -53,7 +70,7 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"or `make -C {_PKG / 'csrc'}`; there is no non-HIP fallback")
         L = ctypes.CDLL(str(LIB_PATH))
-        for name, (res, args) in ABI.items():
+        for name, (res, args) in {**ABI, **CODEC_ABI}.items():
             fn = getattr(L, name)          # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args

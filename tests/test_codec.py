@@ -1,0 +1,155 @@
+"""Latent container + rANS coder.  NEW functionality without a reference
+counterpart, parity "unpinned": the CPU tests pin the oracle's own specification (round trips, header,
+frequency normalisation, corruption detection); the GPU tests show GPU == oracle byte for byte and
+decode(encode(x)) == x on the real latent of the net."""
+import ctypes
+import re
+import struct
+import zlib
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _mock_latent(rng, shape, zero_frac=0.5):
+    """Like the net's latent: ~50 % zeros, the rest uniform on 1..127."""
+    lat = rng.integers(1, 128, shape, dtype=np.uint8)
+    lat[rng.random(shape) < zero_frac] = 0
+    return lat
+
+
+SHAPES = [(16, 16, 192), (1, 1, 192), (3, 5, 7), (0, 4, 4), (2, 2, 1), (8, 3, 192), (64, 1, 16)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_oracle_round_trip(shape, mode):
+    rng = np.random.default_rng(sum(shape) * 3 + mode)
+    lat = _mock_latent(rng, shape)
+    blob = c_oracle.codec_encode(lat, (shape[1] * 16, shape[0] * 16), mode)
+    out, info = c_oracle.codec_decode(blob)
+    assert np.array_equal(out, lat)
+    assert info.tolist()[:6] == [mode, shape[1] * 16, shape[0] * 16, shape[1], shape[0], shape[2]]
+    assert len(blob) <= c_oracle.lib().sicl_or_max_bytes(mode, lat.size)
+
+
+def test_header_fields_and_checksum():
+    lat = _mock_latent(np.random.default_rng(1), (4, 6, 8))
+    blob = c_oracle.codec_encode(lat, (96, 64), 2)
+    magic, ver, mode, iw, ih, lw, lh, lc, n, ns, ss, payload, adler = struct.unpack("<4sHHIIIIIIIIII", blob[:48])
+    assert (magic, ver, mode, iw, ih, lw, lh, lc, n, ns, ss) == (b"SICL", 1, 2, 96, 64, 6, 4, 8, 192, 1, 1024)
+    assert adler == zlib.adler32(lat.tobytes())            # the header checksum is the standard adler32
+    freq = np.frombuffer(blob[48:48 + 256], "<u2")
+    assert int(freq.sum()) == 4096 and all(freq[s] > 0 for s in np.unique(lat))
+    (len0,) = struct.unpack("<I", blob[304:308])
+    assert payload == len0 == len(blob) - 308
+
+
+def test_extreme_distributions_round_trip():
+    rng = np.random.default_rng(2)
+    for lat in (np.zeros((4, 4, 192), np.uint8), np.full((4, 4, 192), 127, np.uint8),
+                np.arange(128, dtype=np.uint8).reshape(1, 1, 128),
+                np.concatenate([np.zeros(5000, np.uint8), np.array([77], np.uint8)]).reshape(1, 1, -1),   # freq 1 symbol
+                rng.integers(0, 128, (5, 41, 6), dtype=np.uint8)):
+        for mode in (0, 1, 2):
+            out, _ = c_oracle.codec_decode(c_oracle.codec_encode(lat, (0, 0), mode))
+            assert np.array_equal(out, lat)
+    # a constant latent costs almost nothing under rANS: 4 state bytes + <= 1 byte per 1024-symbol stream
+    blob = c_oracle.codec_encode(np.zeros((16, 16, 192), np.uint8), (256, 256), 2)
+    assert len(blob) < 48 + 256 + 48 * 4 + 48 * 8
+
+
+def test_rejects_symbols_over_127_and_corruption():
+    lat = _mock_latent(np.random.default_rng(3), (4, 4, 192))
+    bad = lat.copy()
+    bad[0, 0, 0] = 200
+    with pytest.raises(RuntimeError):
+        c_oracle.codec_encode(bad, (0, 0), 2)
+    blob = bytearray(c_oracle.codec_encode(lat, (64, 64), 2))
+    blob[-5] ^= 0x40                                       # flip a payload bit
+    with pytest.raises(RuntimeError):
+        c_oracle.codec_decode(bytes(blob))
+    with pytest.raises(RuntimeError):
+        c_oracle.codec_decode(bytes(blob[:40]))            # truncated header
+
+
+def test_frequency_normalisation_properties():
+    L = c_oracle.lib()
+    rng = np.random.default_rng(4)
+    for _ in range(50):
+        k = int(rng.integers(1, 129))
+        h = np.zeros(128, np.uint32)
+        h[rng.choice(128, k, replace=False)] = rng.integers(1, 1 << int(rng.integers(1, 24)), k)
+        f = np.zeros(128, np.uint16)
+        assert L.sicl_or_normalize(c_oracle._ptr(h), int(h.sum()), c_oracle._ptr(f)) == 0
+        assert int(f.sum()) == 4096 and np.array_equal(f > 0, h > 0)
+
+
+def test_codec_abi_symbols_exported():
+    text = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "sicn_codec.h").read_text(), flags=re.S)
+    syms = sorted(set(re.findall(r"\b(sicn_codec_[a-z0-9_]+)\s*\(", text)))
+    from simple_image_compression_network_amd import _lib
+    L = ctypes.CDLL(str(_lib.LIB_PATH))
+    assert set(syms) == set(_lib.CODEC_ABI) and all(hasattr(L, s) for s in syms)
+    info = _lib.CodecInfo()
+    blob = c_oracle.codec_encode(_mock_latent(np.random.default_rng(5), (2, 3, 4)), (48, 32), 1)
+    buf = (ctypes.c_uint8 * 48).from_buffer_copy(blob[:48])
+    assert _lib.lib().sicn_codec_parse_header(buf, 48, ctypes.byref(info)) == 0        # pure host function
+    assert (info.mode, info.image_width, info.lat_w, info.lat_h, info.lat_c, info.n_symbols) == (1, 48, 3, 2, 4, 24)
+    assert _lib.lib().sicn_codec_parse_header(buf, 10, ctypes.byref(info)) == -22
+
+
+# ------------------------------------------------------------------------------------------ GPU
+gpu = pytest.mark.gpu
+
+
+@gpu
+@pytest.mark.parametrize("shape", SHAPES + [(135, 240, 192)])
+def test_gpu_container_equals_oracle_and_round_trips(shape):
+    import torch
+    from simple_image_compression_network_amd import codec
+    rng = np.random.default_rng(sum(shape))
+    lat = _mock_latent(rng, shape)
+    dev = torch.from_numpy(lat).cuda()
+    for mode in (codec.RAW8, codec.PACKED7, codec.RANS):
+        blob = codec.encode_latent(dev, shape[1] * 16, shape[0] * 16, mode)
+        host = blob.cpu().numpy().tobytes()
+        assert host == c_oracle.codec_encode(lat, (shape[1] * 16, shape[0] * 16), mode), f"mode {mode}"
+        back, info = codec.decode_latent(blob)
+        assert torch.equal(back, dev) and info.mode == mode
+        # and the GPU decoder accepts what the CPU coder wrote
+        back2, _ = codec.decode_latent(torch.frombuffer(bytearray(host), dtype=torch.uint8).cuda())
+        assert torch.equal(back2, dev)
+
+
+@gpu
+def test_gpu_codec_on_real_latent_and_errors():
+    import torch
+    from simple_image_compression_network_amd import _lib, api, codec
+    x = np.random.default_rng(0).integers(0, 256, (1, 512, 768, 3), dtype=np.uint8)
+    net = api.EightLayersNet(768, 512)
+    _, latent = net.forward(torch.from_numpy(x).cuda())
+    blob = codec.encode_latent(latent[0], 768, 512, codec.RANS)
+    back, info = codec.decode_latent(blob)
+    assert torch.equal(back, latent[0])
+    assert (info.lat_w, info.lat_h, info.lat_c, info.image_width) == (48, 32, 192, 768)
+    assert blob.numel() < latent[0].numel()                 # order-0 entropy of this latent is ~4.5 bit/symbol
+    # decoding the decoded latent's reconstruction is the same as without the codec in between
+    out_a, _ = net.run_layers(4, 7, latent)
+    out_b, _ = net.run_layers(4, 7, back[None])
+    assert torch.equal(out_a, out_b)
+    bad = latent[0].clone()
+    bad[0, 0, 0] = 200                                       # symbol >= 128
+    with pytest.raises(_lib.SicnError) as e:
+        codec.encode_latent(bad, 768, 512, codec.RANS)
+    assert e.value.code == -22
+    corrupt = blob.clone()
+    corrupt[-7] ^= 0x10
+    with pytest.raises(_lib.SicnError) as e:
+        codec.decode_latent(corrupt)
+    assert e.value.code in (-22, -74)
