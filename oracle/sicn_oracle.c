@@ -484,6 +484,16 @@ static void unpack_okc(const uint64_t *m_weights, const sicn_or_layer_desc *d, i
             }
 }
 
+/* sum_c s[c]*w[c]; cloned for AVX2 with run-time dispatch (the .so is built on one host and timed on
+ * another, so no -march=native) */
+__attribute__((target_clones("avx2", "default"))) static int32_t dot_u8_i8(const uint8_t *s, const int8_t *w, int n)
+{
+    int32_t a = 0;
+#pragma omp simd reduction(+ : a)
+    for (int c = 0; c < n; c++) a += (int32_t)s[c] * (int32_t)w[c];
+    return a;
+}
+
 int sicn_or_layer_direct(const sicn_or_layer_desc *d, const uint64_t *m_weights, const int8_t *bias,
                          const uint8_t *in, uint8_t *out, int threads)
 {
@@ -521,13 +531,7 @@ int sicn_or_layer_direct(const sicn_or_layer_desc *d, const uint64_t *m_weights,
             for (int o = 0; o < N; o++) {
                 int32_t acc = 0;
                 const int8_t *wo = W + (size_t)o * 25 * C;
-                for (int t = 0; t < nt; t++) {
-                    const uint8_t *s = src[t];
-                    const int8_t *w = wo + wk[t];
-                    int32_t a = 0;
-                    for (int c = 0; c < C; c++) a += (int32_t)s[c] * (int32_t)w[c];
-                    acc += a;
-                }
+                for (int t = 0; t < nt; t++) acc += dot_u8_i8(src[t], wo + wk[t], C);
                 uint8_t v = (uint8_t)((acc + bias[o]) & 0xFF);
                 if (v & 0x80u) v = 0;
                 out[((size_t)y * OW + x) * N + o] = v;
