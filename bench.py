@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--images-per-gpu", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, nargs=2, default=[256, 256], metavar=("W", "H"))
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, one GPU per rank) is the real thing; gloo lets several ranks share one GPU "
+                         "to rehearse the multi-rank path on a 1-GPU box")
     return ap.parse_args()
 
 
@@ -75,10 +78,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
+    dev = torch.device("cuda", local_rank % max(ndev, 1))
+    torch.cuda.set_device(dev)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where the bookkeeping collectives live
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     W, H, B = args.width, args.height, args.images_per_gpu
     # synthetic inputs: uint8 NHWC, i.i.d. uniform 0..255, one seed per global image index
@@ -108,7 +118,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -116,7 +126,7 @@ def main():
     net.profile(False)
 
     # bookkeeping collective only: one checksum per rank so rank 0 can report that every shard ran
-    chk = torch.tensor([int(out.view(-1)[:: 65537].to(torch.int64).sum().item())], dtype=torch.int64, device=dev)
+    chk = torch.tensor([int(out.view(-1)[:: 65537].to(torch.int64).sum().item())], dtype=torch.int64, device=cdev)
     if world > 1:
         chks = [torch.zeros_like(chk) for _ in range(world)]
         dist.all_gather(chks, chk)

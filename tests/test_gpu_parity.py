@@ -277,3 +277,22 @@ def test_cpp_testbench_mirrors_reference_test():
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         assert "Image # 0 passed the testing." in r.stdout
         assert "conv2d_layer0: passed" in r.stdout and "deconv2d_layer4: passed" in r.stdout
+
+
+def test_bench_two_ranks_on_one_gpu_rehearsal():
+    """bench.py under torch.distributed.run with 2 ranks (gloo, both on cuda:0): the rank / barrier / MAX-over-ranks /
+    rank-0-prints-one-JSON-line logic of the N>1 path, which the driver runs with nccl on a real multi-GPU node."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+           "--width", "256", "--height", "128", "--images-per-gpu", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_images"] == 4
+    assert d["value"] > 0 and "cpu_baseline" not in d and d["roofline"]["frac"] > 0
