@@ -44,11 +44,11 @@ namespace sicn {
 //  host-side instantiation of the kernel fail with a silent substitution failure, ROCm 7.2)
 
 template <int TB>
-__device__ __forceinline__ void load_wtile(uint8_t *ring, const int8_t *wstream, int step, int lane, int w)
+__device__ __forceinline__ void load_wtile(uint8_t *ring, const int8_t *wstream, int tile, int seq, int lane, int w)
 {
     constexpr int NPB = TB / 1024, WR = (NPB + 3) / 4;
-    const int8_t *src = wstream + (size_t)step * TB + lane * 16;
-    uint8_t *dst = ring + (step % RING) * TB;
+    const int8_t *src = wstream + (size_t)tile * TB + lane * 16;   // `tile` = index in the weight stream
+    uint8_t *dst = ring + (seq % RING) * TB;                       // `seq` = position in this block's K walk
 #pragma unroll
     for (int r = 0; r < WR; r++) {
         int piece = r * 4 + w;
@@ -161,7 +161,7 @@ __device__ __forceinline__ void store_tiles(const v16i (&acc)[2][NTJ], uint8_t *
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         const int gy = Y0 + 2 * w + i, gx = X0 + m;
-        if (gy < MH && gx < MW && !(dbg & 1)) {
+        if (gy < MH && gx < MW && !(dbg & 1)) {  // dbg: timing diagnostics only
             const int oy_ = deconv ? 2 * gy + py : gy, ox_ = deconv ? 2 * gx + px : gx;
 #pragma unroll
             for (int j = 0; j < NTJ; j++) {
@@ -171,7 +171,9 @@ __device__ __forceinline__ void store_tiles(const v16i (&acc)[2][NTJ], uint8_t *
                 v.y = pack4_relu7(a[4], a[5], a[6], a[7]);
                 v.z = pack4_relu7(a[8], a[9], a[10], a[11]);
                 v.w = pack4_relu7(a[12], a[13], a[14], a[15]);
-                *(uint4 *)(out_img + tensor_offset(out_layout, oy_, ox_, (uint32_t)j, COUT, OW, OH) + 16 * kh) = v;
+                uint32_t off = tensor_offset(out_layout, oy_, ox_, (uint32_t)j, COUT, OW, OH) + 16 * kh;
+                if (dbg & 4) off &= 0xFFFFu;   // diagnostic: all stores land in one 64 KiB window (stay in L2)
+                *(uint4 *)(out_img + off) = v;
             }
         }
     }
@@ -231,7 +233,7 @@ __device__ __forceinline__ void conv_steps(const StepCtx<NTJ> &c, const uint32_t
         load_piece(c.patch, c.in_img, c.in_img_bytes, rp, slot * 4 + c.w, poff[rp][slot] + (uint32_t)qq * qstride);
     }
     // (2) weight ring top-up (the stream is padded with PF dummy tiles)
-    load_wtile<TB>(c.ring, c.wstream, step + PF, c.lane, c.w);
+    load_wtile<TB>(c.ring, c.wstream, step + PF, step + PF, c.lane, c.w);
     // (3) MFMAs of this step around the barrier that publishes weight tile step+1 (issued 2 steps
     //     ago, before that step's B pieces) and every patch piece issued before it
     k_step<NTJ, (PF - 1) * WR + refresh_count(TT), VARIANT>(
@@ -239,6 +241,76 @@ __device__ __forceinline__ void conv_steps(const StepCtx<NTJ> &c, const uint32_t
         tap.kx >> 1, c.patch + nxt_plane * SUB_ALLOC, c.ring + ((step + 1) % RING) * TB, nxt.ky >> 1, nxt.kx >> 1,
         c.wrow, c.p_lane, c.kh);
     if constexpr (T + 1 < 50) conv_steps<NTJ, VARIANT, T + 1>(c, poff, q0, qstride);
+}
+
+struct DeconvIo {
+    uint8_t *out_img;
+    const int8_t *bias;
+    int OW, OH, MW, MH, Y0, X0, m, out_layout, dbg;
+};
+
+__host__ __device__ constexpr int phase_first_tap(int ph) { return ph == 0 ? 0 : ph == 1 ? 9 : ph == 2 ? 15 : 21; }
+__host__ __device__ constexpr int phase_taps(int ph) { return (3 - (ph >> 1)) * (3 - (ph & 1)); }
+
+// The 4 deconv phases in the order (ROT, ROT+1, ROT+2, ROT+3) mod 4.  The weight stream is stored in
+// phase order 0,1,2,3, so the tile consumed at position `seq` of this walk is a compile-time base plus a
+// run-time offset, and the prefetch PF steps ahead may already belong to the next phase of the walk.
+template <int NTJ, int NQ, int VARIANT, int ROT>
+__device__ __forceinline__ void deconv_phases(const StepCtx<NTJ> &c, const DeconvIo &io)
+{
+    constexpr int TB = NTJ * 32 * KSTEP, WR = (TB / 1024 + 3) / 4, STEPS = 25 * NQ;
+    // first PF tiles of the walk (phase ROT has >= 16 steps >= PF)
+#pragma unroll
+    for (int s = 0; s < PF; s++) load_wtile<TB>(c.ring, c.wstream, phase_first_tap(ROT) * NQ + s, s, c.lane, c.w);
+    wait_vmcnt<0>();
+    block_barrier();
+    if constexpr (VARIANT == 1)
+        load_frags<NTJ>(c.fr[0], c.patch, c.ring, c.wrow, c.p_lane, c.kh, ROT >> 1, ROT & 1);  // step 0
+    int seq = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int ph = (ROT + k) & 3, nph = (ROT + k + 1) & 3;
+        const int py = ph >> 1, px = ph & 1;
+        const int nkx = 3 - px, ntap = (3 - py) * nkx;
+        const int npy = nph >> 1, npx = nph & 1;   // first tap of the next phase of this walk
+        const int len = ntap * NQ;
+        const int base = phase_first_tap(ph) * NQ;                       // stream tile of local step 0
+        const int nbase = k < 3 ? phase_first_tap(nph) * NQ : STEPS;     // next phase, or the zero padding
+        init_acc<NTJ>(c.acc, io.bias, c.kh);
+#pragma unroll 1
+        for (int t = 0; t < ntap; t++) {
+            const int iy = t / nkx, ix = t - iy * nkx;
+            int noy, nox;   // coordinates of the tap after this one (for the last group's prefetch)
+            if (t + 1 < ntap) {
+                const int t1 = t + 1, iy1 = t1 / nkx;
+                noy = iy1 + py;
+                nox = t1 - iy1 * nkx + px;
+            } else {
+                noy = npy;
+                nox = npx;
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const int j = t * NQ + q + PF;   // local index of the tile to prefetch
+                load_wtile<TB>(c.ring, c.wstream, j < len ? base + j : nbase + (j - len), seq + q + PF, c.lane, c.w);
+                const bool last = (q == NQ - 1);
+                // the 2*NTJ output stores of the previous phase sit between the awaited weight tile
+                // and this step for the first PF-1 steps of a phase: count them, do not wait for them
+                k_step<NTJ, (PF - 1) * WR, VARIANT, 2 * NTJ>(c.acc, c.fr[q & 1], c.fr[(q + 1) & 1], c.patch + q * SUB_ALLOC,
+                                                             c.ring + ((seq + q) % RING) * TB, iy + py, ix + px,
+                                                             c.patch + (last ? 0 : q + 1) * SUB_ALLOC,
+                                                             c.ring + ((seq + q + 1) % RING) * TB, last ? noy : iy + py,
+                                                             last ? nox : ix + px, c.wrow, c.p_lane, c.kh,
+                                                             k > 0 && t == 0 && q < PF - 1);
+            }
+            seq += NQ;
+        }
+        if (k == 3) wait_vmcnt<0>();  // the padded tail of the weight prefetch must land before exit
+        store_tiles<NTJ>(c.acc, io.out_img, io.OW, io.OH, io.MW, io.MH, io.Y0, io.X0, c.w, io.m, c.kh, true, py, px,
+                         io.out_layout, io.dbg);
+    }
 }
 
 template <int NQ, int NTJ, bool DECONV, int MINW, int VARIANT>
@@ -275,6 +347,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_t(
     Frags<NTJ> fr[2];
     const int p_lane = (2 * w) * PATCH_X + m;
     const StepCtx<NTJ> ctx{acc, fr, patch, ring, wstream, wrow, in_img, in_img_bytes, p_lane, kh, lane, w};
+    (void)bias;
 
     if constexpr (DECONV) {
         // ---- prologue: the whole patch (NQ channel groups) + PF weight tiles --------------------
@@ -286,50 +359,18 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_t(
                            piece_src_offset(slot * 4 + w, lane, Y0 - 1, X0 - 1, 1, 0, 0, IW, IH, in_layout,
                                             (uint32_t)sub, CIN));
 #pragma unroll
-        for (int s = 0; s < PF; s++) load_wtile<TB>(ring, wstream, s, lane, w);
+        for (int s = 0; s < PF; s++) load_wtile<TB>(ring, wstream, s, s, lane, w);
         wait_vmcnt<0>();
         block_barrier();
         if constexpr (VARIANT == 1) load_frags<NTJ>(fr[0], patch, ring, wrow, p_lane, kh, 0, 0);  // step 0
 
-        constexpr int WR = (TB / 1024 + 3) / 4;
-        int step = 0;
-#pragma unroll
-        for (int ph = 0; ph < 4; ph++) {
-            const int py = ph >> 1, px = ph & 1;
-            const int nkx = 3 - px, ntap = (3 - py) * nkx;
-            const int npy = (ph + 1) >> 1, npx = (ph + 1) & 1;   // first tap of the next phase
-            init_acc<NTJ>(acc, bias, kh);
-#pragma unroll 1
-            for (int t = 0; t < ntap; t++) {
-                const int iy = t / nkx, ix = t - iy * nkx;
-                // coordinates of the tap after this one (for the last group's prefetch)
-                int noy, nox;
-                if (t + 1 < ntap) {
-                    const int t1 = t + 1, iy1 = t1 / nkx;
-                    noy = iy1 + py;
-                    nox = t1 - iy1 * nkx + px;
-                } else {
-                    noy = npy;
-                    nox = npx;
-                }
-#pragma unroll
-                for (int q = 0; q < NQ; q++) {
-                    load_wtile<TB>(ring, wstream, step + q + PF, lane, w);
-                    const bool last = (q == NQ - 1);
-                    // the 2*NTJ output stores of the previous phase sit between the awaited weight tile
-                    // and this step for the first PF-1 steps of a phase: count them, do not wait for them
-                    k_step<NTJ, (PF - 1) * WR, VARIANT, 2 * NTJ>(acc, fr[q & 1], fr[(q + 1) & 1], patch + q * SUB_ALLOC,
-                                                                 ring + ((step + q) % RING) * TB, iy + py, ix + px,
-                                                                 patch + (last ? 0 : q + 1) * SUB_ALLOC,
-                                                                 ring + ((step + q + 1) % RING) * TB, last ? noy : iy + py,
-                                                                 last ? nox : ix + px, wrow, p_lane, kh,
-                                                                 ph > 0 && t == 0 && q < PF - 1);
-                }
-                step += NQ;
-            }
-            if (ph == 3) wait_vmcnt<0>();  // the padded tail of the weight prefetch must land before exit
-            store_tiles<NTJ>(acc, out_img, OW, OH, MW, MH, Y0, X0, w, m, kh, true, py, px, out_layout, dbg);
-        }
+        // Phase order: rotation 0 or 2, chosen per workgroup when dbg bit 1 is set (experiment:
+        // co-resident workgroups then reach their store bursts at different times).
+        const DeconvIo io{out_img, bias, OW, OH, MW, MH, Y0, X0, m, out_layout, dbg};
+        if ((dbg & 2) && (blockIdx.x & 1))
+            deconv_phases<NTJ, NQ, VARIANT, 2>(ctx, io);
+        else
+            deconv_phases<NTJ, NQ, VARIANT, 0>(ctx, io);
     } else {
         static_assert(DECONV || NQ % 2 == 0, "conv walks channel groups in pairs");
         // ---- per-lane source offsets of the 4 planes x 3 refresh slots (channel group 0) --------
@@ -348,7 +389,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma_t(
             for (int slot = 0; slot < 3; slot++)
                 load_piece(patch, in_img, in_img_bytes, pl, slot * 4 + w, poff[pl][slot]);
 #pragma unroll
-        for (int s = 0; s < PF; s++) load_wtile<TB>(ring, wstream, s, lane, w);
+        for (int s = 0; s < PF; s++) load_wtile<TB>(ring, wstream, s, s, lane, w);
         wait_vmcnt<0>();
         block_barrier();
         if constexpr (VARIANT == 1) load_frags<NTJ>(fr[0], patch, ring, wrow, p_lane, kh, 0, 0);  // step 0
