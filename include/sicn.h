@@ -35,6 +35,9 @@
  * after creation; concurrent launches on different streams are allowed provided each uses its own
  * workspace.
  *
+ * Size limits of the specialised kernels (SICN_EINVAL beyond them): one image's input < 2 GiB and
+ * output < 4 GiB per layer (32-bit offsets inside an image; 8K RGB images fit), n_images <= 65535.
+ *
  * Naming trap inherited from the reference: IFM_ROW / OFM_ROW are WIDTHS (x, fast dimension),
  * IFM_COL / OFM_COL are HEIGHTS (conv_nonsquare_top.cpp:283-285).
  */

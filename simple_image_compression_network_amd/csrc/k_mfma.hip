@@ -461,7 +461,8 @@ bool mfma_supported(int cin, int cout, int transposed)
 hipError_t launch_mfma(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
                        int n_images, hipStream_t stream, int in_layout, int out_layout)
 {
-    if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB) return hipErrorInvalidValue;
+    if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB) return hipErrorInvalidValue;          // 31-bit patch offsets
+    if ((size_t)g.OH * g.OW * g.COUT >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // 32-bit store offsets
     if (g.transposed) {
         if (g.CIN == 128 && g.COUT == 128) return launch_one<4, 4, true>(g, w, in, out, n_images, stream, in_layout, out_layout);
         if (g.CIN == 192 && g.COUT == 128) return launch_one<6, 4, true>(g, w, in, out, n_images, stream, in_layout, out_layout);

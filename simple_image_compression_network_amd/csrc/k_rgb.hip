@@ -208,6 +208,7 @@ hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
     y_chunks = y_chunks < 1 ? 1 : (y_chunks > tiles_y ? tiles_y : y_chunks);
     dim3 grid((unsigned)tiles_x, (unsigned)y_chunks, (unsigned)n_images);
     if ((size_t)g.IH * g.IW * 3 * (size_t)n_images + 4 >= (size_t)OOB) return hipErrorInvalidValue;
+    if ((size_t)g.OH * g.OW * g.COUT >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // 32-bit store offsets
     if (g.COUT == 128) {
         const size_t lds = 5 * 128 * KSTEP + 2 * L0_PATCH;
         hipLaunchKernelGGL(k_l0<4>, grid, dim3(256), lds, stream, in, out, w.d_w_l0, w.d_bias, g.IW, g.IH,
