@@ -296,3 +296,11 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_images"] == 4
     assert d["value"] > 0 and "cpu_baseline" not in d and d["roofline"]["frac"] > 0
+
+
+def test_committed_small_vectors_on_gpu(api):
+    """The HIP path against the committed fixture tests/golden/small_vectors.npz (no oracle call at all)."""
+    from test_oracle_golden import _small_vectors
+    for d, words, bias, x, y in _small_vectors():
+        got = _run_layer(api, d, words, bias, x[None])
+        assert np.array_equal(got[0], y), d

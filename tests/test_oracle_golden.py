@@ -149,3 +149,24 @@ def test_oracle_rejects_bad_descs(param_words):
     with pytest.raises(RuntimeError):
         c_oracle.run_layer(bad, param_words[1][0], param_words[1][1],
                            np.zeros(d.in_shape, np.uint8), "direct")
+
+
+def _small_vectors():
+    from dataclasses import fields
+    z = np.load(GOLDEN / "small_vectors.npz")
+    k = 0
+    while f"d{k}" in z:
+        d = LayerDesc(**{f.name: int(v) for f, v in zip(fields(LayerDesc), z[f"d{k}"])})
+        yield d, z[f"words{k}"], z[f"bias{k}"], z[f"x{k}"], z[f"y{k}"]
+        k += 1
+
+
+def test_committed_small_vectors_still_hold():
+    """tests/golden/small_vectors.npz (made by make_small_vectors.py from the pinned oracle): every CPU form
+    must still reproduce the stored outputs byte for byte."""
+    n = 0
+    for d, words, bias, x, y in _small_vectors():
+        for form in ("dataflow_im2col", "naive", "direct"):
+            assert np.array_equal(c_oracle.run_layer(d, words, bias, x, form), y), (d, form)
+        n += 1
+    assert n == 7
