@@ -304,3 +304,28 @@ def test_committed_small_vectors_on_gpu(api):
     for d, words, bias, x, y in _small_vectors():
         got = _run_layer(api, d, words, bias, x[None])
         assert np.array_equal(got[0], y), d
+
+
+def test_forward_is_graph_capturable(api):
+    """sicn.h promises that launch functions neither allocate nor synchronise: capture the 8-layer chain into a
+    hipGraph (torch.cuda.CUDAGraph), replay it on new input and compare with the eager result."""
+    net = api.EightLayersNet(256, 256)
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy(rng.integers(0, 256, (2, 256, 256, 3), dtype=np.uint8)).cuda()
+    out = torch.empty((2, 256, 256, 3), dtype=torch.uint8, device="cuda")
+    lat = torch.empty((2, 16, 16, 192), dtype=torch.uint8, device="cuda")
+    net.forward(x, out, lat)                      # warm-up outside capture (workspace allocation, module load)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(graph, stream=s):
+            net.forward(x, out, lat)
+    x2 = torch.from_numpy(rng.integers(0, 256, (2, 256, 256, 3), dtype=np.uint8)).cuda()
+    x.copy_(x2)
+    graph.replay()
+    torch.cuda.synchronize()
+    got_out, got_lat = out.clone(), lat.clone()
+    ref_out, ref_lat = net.forward(x2)
+    torch.cuda.synchronize()
+    assert torch.equal(got_out, ref_out) and torch.equal(got_lat, ref_lat)
