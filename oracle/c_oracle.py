@@ -128,3 +128,28 @@ def run_net(descs, words_list, bias_list, x: np.ndarray, form: str = "dataflow",
         x = run_layer(d, w, b, x, form, threads)
         outs.append(x)
     return outs
+
+
+
+class OrConvLayerDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("K", "IFM_CH", "IFM_DIM", "OFM_CH", "OFM_DIM", "SIMD", "PE", "IN_BIT", "IN_SIGNED",
+                                              "W_BIT", "W_TILES", "ACC_BIT", "ACC_SIGNED", "OUT_BIT", "activation", "NUM_TH",
+                                              "ACT_VAL")]
+
+
+def convlayer_dataflow(cdesc, words: np.ndarray, thresholds, x: np.ndarray, use_fsm: bool = True) -> np.ndarray:
+    """ConvLayer_Batch as the dataflow runs it (sicn_or_convlayer_dataflow). cdesc: any object with the
+    sicn_convlayer_desc fields. Returns uint32 [OFM_DIM][OFM_DIM][OFM_CH] (low OUT_BIT bits of each lane)."""
+    d = OrConvLayerDesc(**{n: int(getattr(cdesc, n)) for n, _ in OrConvLayerDesc._fields_})
+    L = lib()
+    L.sicn_or_convlayer_dataflow.restype = ctypes.c_int
+    L.sicn_or_convlayer_dataflow.argtypes = [ctypes.POINTER(OrConvLayerDesc)] + [ctypes.c_void_p] * 4 + [ctypes.c_int]
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    x = np.ascontiguousarray(x, dtype=np.uint8)
+    out = np.zeros((d.OFM_DIM, d.OFM_DIM, d.OFM_CH), np.uint32)
+    th = np.ascontiguousarray(thresholds, dtype=np.int32) if thresholds is not None else None
+    rc = L.sicn_or_convlayer_dataflow(ctypes.byref(d), _ptr(words), _ptr(th) if th is not None else None, _ptr(x), _ptr(out),
+                                      int(use_fsm))
+    if rc:
+        raise RuntimeError(f"sicn_or_convlayer_dataflow rc={rc}")
+    return out

@@ -540,3 +540,83 @@ int sicn_or_layer_direct(const sicn_or_layer_desc *d, const uint64_t *m_weights,
     free(W);
     return SICN_OR_OK;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* ConvLayer_Batch (convlayer.h:89-125) — the generic finn-hlslib layer, restated as the         */
+/* dataflow runs it: square ConvolutionInputGenerator (slidingwindow.h:163-270; same FSM as the  */
+/* non-square one with IFMDim_x = IFMDim_y, stride 1, NO padding) -> Matrix_Vector_Activate_Batch */
+/* with TA = ap_int/ap_uint<ACC_BIT> wrapping at every += (mvau.hpp:112,149-156; mac.hpp:163-172) */
+/* and PassThroughActivation (activations.hpp:127-134) or ThresholdsActivation                   */
+/* (activations.hpp:168-190: result = ActVal + #{i : m_thresholds[pe][nf][i] < accu}).           */
+/* The reference never executes this surface (conv_nonsquare_top.cpp:223 is commented out):      */
+/* parity UNPINNED.  Field order = include/sicn_convlayer.h sicn_convlayer_desc.                 */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t K, IFM_CH, IFM_DIM, OFM_CH, OFM_DIM, SIMD, PE, IN_BIT, IN_SIGNED, W_BIT, W_TILES;
+    int32_t ACC_BIT, ACC_SIGNED, OUT_BIT, activation, NUM_TH, ACT_VAL;
+} sicn_or_convlayer_desc;
+
+static int64_t wrap_bits(int64_t v, int bits, int is_signed)
+{
+    const uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
+    uint64_t u = (uint64_t)v & mask;
+    if (is_signed && bits < 64 && ((u >> (bits - 1)) & 1)) return (int64_t)(u | ~mask);
+    return (int64_t)u;
+}
+
+/* out: uint32 per lane = the low OUT_BIT bits of the activation result */
+int sicn_or_convlayer_dataflow(const sicn_or_convlayer_desc *d, const uint64_t *m_weights /* [PE][TILES] */,
+                               const int32_t *thresholds /* [PE][NF][NUM_TH] or NULL */, const uint8_t *in,
+                               uint32_t *out, int use_fsm)
+{
+    if (d->IFM_CH % d->SIMD || d->OFM_CH % d->PE || d->OFM_DIM != d->IFM_DIM - d->K + 1 || d->IN_BIT != 8)
+        return SICN_OR_EINVAL;
+    const int C = d->IFM_CH, K = d->K, kk = K * K * C, sf_n = kk / d->SIMD, nf_n = d->OFM_CH / d->PE;
+    if (d->W_TILES != nf_n * sf_n || d->SIMD * d->W_BIT > 64) return SICN_OR_EINVAL;
+    const long long windows = (long long)d->OFM_DIM * d->OFM_DIM;
+    uint8_t *conv_inp = (uint8_t *)malloc((size_t)windows * kk);
+    int64_t *accu = (int64_t *)malloc(sizeof(int64_t) * (size_t)d->PE);
+    if (!conv_inp || !accu) { free(conv_inp); free(accu); return SICN_OR_ENOMEM; }
+    int rc = SICN_OR_OK;
+    if (use_fsm) {
+        long long n = sicn_or_swg_nonsquare_fsm(in, (long long)d->IFM_DIM * d->IFM_DIM * (C / d->SIMD), conv_inp, K, K, C,
+                                                d->IFM_DIM, d->IFM_DIM, d->OFM_DIM, d->OFM_DIM, d->SIMD, 1, 1);
+        if (n != windows * K * K * (C / d->SIMD)) rc = n < 0 ? (int)n : SICN_OR_EUNDERRUN;
+    } else
+        sicn_or_im2col_s1(in, conv_inp, K, C, d->IFM_DIM, d->OFM_DIM, d->OFM_DIM);
+    const uint64_t wmask = (1ull << d->W_BIT) - 1;
+    for (long long r = 0; r < windows && !rc; r++) {
+        const uint8_t *vec = conv_inp + (size_t)r * kk;
+        int tile = 0;
+        for (int nf = 0; nf < nf_n; nf++) {
+            for (int pe = 0; pe < d->PE; pe++) accu[pe] = 0;
+            for (int sf = 0; sf < sf_n; sf++, tile++)
+                for (int pe = 0; pe < d->PE; pe++) {
+                    const uint64_t word = m_weights[(size_t)pe * d->W_TILES + tile];
+                    int64_t res = accu[pe];
+                    for (int s = 0; s < d->SIMD; s++) {
+                        int w = (int)((word >> (d->W_BIT * s)) & wmask);
+                        if (w >> (d->W_BIT - 1)) w -= 1 << d->W_BIT;
+                        const int x = d->IN_SIGNED ? (int)(int8_t)vec[sf * d->SIMD + s] : (int)vec[sf * d->SIMD + s];
+                        res = wrap_bits(res + (int64_t)w * x, d->ACC_BIT, d->ACC_SIGNED); /* T res += ...; T = TA */
+                    }
+                    accu[pe] = res;
+                }
+            for (int pe = 0; pe < d->PE; pe++) {
+                int64_t result = accu[pe];
+                if (d->activation == 1) {
+                    result = d->ACT_VAL;
+                    for (int i = 0; i < d->NUM_TH; i++) {
+                        const int64_t th = wrap_bits(thresholds[((size_t)pe * nf_n + nf) * d->NUM_TH + i], d->ACC_BIT, d->ACC_SIGNED);
+                        result += (th < accu[pe]) ? 1 : 0;
+                    }
+                }
+                const uint64_t omask = d->OUT_BIT >= 32 ? 0xFFFFFFFFull : ((1ull << d->OUT_BIT) - 1);
+                out[(size_t)r * d->OFM_CH + nf * d->PE + pe] = (uint32_t)((uint64_t)result & omask);
+            }
+        }
+    }
+    free(conv_inp);
+    free(accu);
+    return rc;
+}

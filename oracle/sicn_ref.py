@@ -143,3 +143,38 @@ def load_param_fixture(path) -> List[Tuple[np.ndarray, np.ndarray, int]]:
         assert wbit == 4 and tiles == (cout // pe) * (25 * cin // simd)
         out.append((unpack_finn_tiles(z[f"w{n}_words"], simd, pe, cin, cout), z[f"b{n}"].copy(), tr))
     return out
+
+
+
+# ------------------------------------------------------------------------------------------
+# Generic ConvLayer_Batch (convlayer.h:89-125) — closed form; parity unpinned (never run by the reference)
+# ------------------------------------------------------------------------------------------
+def pack_finn_tiles_generic(w_ok: np.ndarray, simd: int, pe: int, w_bit: int) -> np.ndarray:
+    """W[o][k] (signed, fits w_bit) -> FixedPointWeights words uint64 [PE][TILES] (weights.hpp:110-150)."""
+    cout, kk = w_ok.shape
+    sf_n, nf_n = kk // simd, cout // pe
+    el = (w_ok.reshape(nf_n, pe, sf_n, simd).astype(np.int64) & ((1 << w_bit) - 1)).astype(np.uint64)
+    shifts = (np.arange(simd, dtype=np.uint64) * np.uint64(w_bit))
+    words = (el << shifts[None, None, None, :]).sum(axis=3, dtype=np.uint64)
+    return np.ascontiguousarray(words.transpose(1, 0, 2).reshape(pe, nf_n * sf_n))
+
+
+def _wrap(v: np.ndarray, bits: int, signed: bool) -> np.ndarray:
+    u = v.astype(np.int64) & ((1 << bits) - 1)
+    return np.where(u >> (bits - 1) & 1, u - (1 << bits), u) if signed else u
+
+
+def conv_layer_batch_ref(x: np.ndarray, w_ok: np.ndarray, k: int, in_signed: bool, acc_bit: int, acc_signed: bool,
+                         out_bit: int, thresholds_oi=None, act_val: int = 0) -> np.ndarray:
+    """x [D][D][C] uint8 lanes, w_ok [O][k*k*C] with K index (ky*k+kx)*C + c (slidingwindow.h:163-270 emits
+    ky -> kx -> channel).  Stride 1, no padding.  thresholds_oi: [O][NumTH] in channel order, or None for
+    PassThroughActivation.  Returns uint32 lanes holding the low out_bit bits."""
+    d, _, c = x.shape
+    od = d - k + 1
+    xs = x.view(np.int8).astype(np.int64) if in_signed else x.astype(np.int64)
+    cols = np.stack([xs[ky:ky + od, kx:kx + od, :] for ky in range(k) for kx in range(k)], axis=2).reshape(od * od, k * k * c)
+    acc = _wrap(cols @ w_ok.astype(np.int64).T, acc_bit, acc_signed)
+    if thresholds_oi is not None:
+        th = _wrap(np.asarray(thresholds_oi), acc_bit, acc_signed)                 # TA m_thresholds
+        acc = act_val + (th[None, :, :] < acc[:, :, None]).sum(axis=2)
+    return (acc & ((1 << out_bit) - 1)).astype(np.uint32).reshape(od, od, -1)

@@ -42,6 +42,22 @@ class CodecInfo(ctypes.Structure):
                                                "n_symbols", "n_streams", "payload_bytes", "adler32")]
 
 
+class CConvLayerDesc(ctypes.Structure):
+    """ctypes image of `sicn_convlayer_desc` (include/sicn_convlayer.h)."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("K", "IFM_CH", "IFM_DIM", "OFM_CH", "OFM_DIM", "SIMD", "PE", "IN_BIT", "IN_SIGNED",
+                                              "W_BIT", "W_TILES", "ACC_BIT", "ACC_SIGNED", "OUT_BIT", "activation", "NUM_TH",
+                                              "ACT_VAL")]
+
+
+_cldp = ctypes.POINTER(CConvLayerDesc)
+# include/sicn_convlayer.h (the generic ConvLayer_Batch surface of convlayer.h:89-125)
+CONVLAYER_ABI = {
+    "sicn_convlayer_validate": (_i, [_cldp]),
+    "sicn_convlayer_params_create": (_i, [_cldp, _vp, _i, _vp, ctypes.POINTER(_vp)]),
+    "sicn_convlayer_params_free": (None, [_vp]),
+    "sicn_conv_layer_batch": (_i, [_cldp, _vp, _vp, _vp, _i, _vp]),
+}
+
 _u32 = ctypes.c_uint32
 # include/sicn_codec.h (extension beyond the reference: latent container + rANS coder)
 CODEC_ABI = {
@@ -70,7 +86,7 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"or `make -C {_PKG / 'csrc'}`; there is no non-HIP fallback")
         L = ctypes.CDLL(str(LIB_PATH))
-        for name, (res, args) in {**ABI, **CODEC_ABI}.items():
+        for name, (res, args) in {**ABI, **CODEC_ABI, **CONVLAYER_ABI}.items():
             fn = getattr(L, name)          # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args

@@ -37,8 +37,8 @@ class FixedPointWeights:
     words, element s of a word = sign-extended nibble in bits [4s, 4s+4)."""
 
     def __init__(self, SIMD: int, W_BIT: int, PE: int, TILES: int, m_weights):
-        if W_BIT != 4 and not (SIMD == 1 and W_BIT == 8):
-            raise ValueError("only ap_int<4> weight tiles and ap_int<8> bias tiles exist in the reference")
+        if not 2 <= W_BIT <= 8 or SIMD * W_BIT > 64:
+            raise ValueError("W_BIT must be 2..8 and SIMD*W_BIT <= 64 (the net itself uses ap_int<4> tiles, ap_int<8> biases)")
         self.SIMD, self.W_BIT, self.PE, self.TILES = SIMD, W_BIT, PE, TILES
         self.m_weights = np.ascontiguousarray(m_weights, dtype=np.uint64).reshape(PE, TILES)
 

@@ -1,0 +1,103 @@
+"""Generic ConvLayer_Batch surface (convlayer.h:89-125).  The reference never runs
+it (conv_nonsquare_top.cpp:223 is commented out), so parity is unpinned: the CPU tests show the dataflow
+restatement (square sliding-window FSM + folded MVAU with a wrapping TA accumulator + activation functor)
+equals the closed form; the GPU tests show the HIP kernel equals both."""
+import ctypes
+import re
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle, sicn_ref
+
+ROOT = Path(__file__).resolve().parent.parent
+
+# (K, C, D, O, SIMD, PE, W_BIT, IN_SIGNED, ACC_BIT, ACC_SIGNED, OUT_BIT, NUM_TH, ACT_VAL)
+CASES = [
+    (3, 4, 9, 6, 2, 3, 4, 0, 16, 1, 16, 0, 0),       # BNN-pynq style conv, 16-bit signed accumulator passed through
+    (5, 3, 12, 8, 3, 4, 4, 0, 8, 0, 8, 0, 0),        # the net's own arithmetic (ap_uint<8> accumulator) without padding
+    (1, 8, 5, 4, 8, 2, 8, 1, 32, 1, 32, 0, 0),       # 1x1, signed inputs, 8-bit weights, full 32-bit result
+    (3, 6, 8, 4, 3, 2, 2, 1, 12, 1, 16, 0, 0),       # 2-bit weights, 12-bit wrapping accumulator
+    (3, 4, 9, 6, 4, 2, 4, 0, 16, 1, 8, 3, 0),        # 3 thresholds -> 2-bit activations
+    (2, 8, 7, 12, 8, 6, 3, 1, 10, 1, 8, 15, -8),     # 15 thresholds, ActVal -8 (signed 4-bit result in a byte lane)
+    (7, 2, 10, 2, 2, 1, 5, 0, 24, 0, 32, 1, 0),      # one threshold (sign), unsigned accumulator compare
+]
+
+
+def _make(case, rng):
+    K, C, D, O, SIMD, PE, WB, INS, AB, AS, OB, NTH, AV = case
+    nf = O // PE
+    w = rng.integers(-(1 << (WB - 1)), 1 << (WB - 1), (O, K * K * C)).astype(np.int8)
+    words = sicn_ref.pack_finn_tiles_generic(w, SIMD, PE, WB)
+    x = rng.integers(0, 256, (D, D, C), dtype=np.uint8)
+    thr = None
+    if NTH:
+        lim = min(1 << (AB - 1), 4000)
+        thr = np.sort(rng.integers(-lim if AS else 0, lim, (PE, nf, NTH)), axis=2).astype(np.int32)
+    desc = SimpleNamespace(K=K, IFM_CH=C, IFM_DIM=D, OFM_CH=O, OFM_DIM=D - K + 1, SIMD=SIMD, PE=PE, IN_BIT=8, IN_SIGNED=INS,
+                           W_BIT=WB, W_TILES=nf * (K * K * C // SIMD), ACC_BIT=AB, ACC_SIGNED=AS, OUT_BIT=OB,
+                           activation=int(NTH > 0), NUM_TH=NTH, ACT_VAL=AV)
+    thr_oi = None if thr is None else thr.transpose(1, 0, 2).reshape(O, NTH)     # [pe][nf] -> o = nf*PE + pe
+    ref = sicn_ref.conv_layer_batch_ref(x, w, K, bool(INS), AB, bool(AS), OB, thr_oi, AV)
+    return desc, w, words, x, thr, ref
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_dataflow_restatement_equals_closed_form(case):
+    rng = np.random.default_rng(abs(hash(case)) % (1 << 32))
+    desc, _, words, x, thr, ref = _make(case, rng)
+    for fsm in (True, False):
+        assert np.array_equal(c_oracle.convlayer_dataflow(desc, words, thr, x, use_fsm=fsm), ref)
+
+
+def test_net_layer_without_padding_is_a_special_case(param_words):
+    """conv2d<> = pad + ConvLayer-style sliding window + decimation: feeding the PADDED image to the generic
+    layer (K=5, ap_uint<8> accumulator, pass-through) and keeping even rows/cols, then bias/ReLU, must give
+    layer 0 of the net (conv_nonsquare_top.cpp:198-280)."""
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (20, 20, 3), dtype=np.uint8)
+    words, bias = param_words[0]
+    w = sicn_ref.unpack_finn_tiles(words, 3, 8, 3, 128)
+    xpad = np.pad(x, ((2, 2), (2, 2), (0, 0)))
+    full = sicn_ref.conv_layer_batch_ref(xpad, w.reshape(128, 75), 5, False, 8, False, 8)
+    v = (full[::2, ::2].astype(np.int64) + bias.astype(np.int64)) & 0xFF
+    v[v >= 128] = 0
+    assert np.array_equal(v.astype(np.uint8), sicn_ref.conv2d_ref(x, w, bias))
+
+
+def test_convlayer_abi_symbols_and_validation():
+    from simple_image_compression_network_amd import _lib
+    text = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "sicn_convlayer.h").read_text(), flags=re.S)
+    syms = sorted(set(re.findall(r"\b(sicn_conv[a-z0-9_]*)\s*\(", text)))
+    L = ctypes.CDLL(str(_lib.LIB_PATH))
+    assert set(syms) == set(_lib.CONVLAYER_ABI) and all(hasattr(L, s) for s in syms)
+    from simple_image_compression_network_amd.convlayer import ConvLayerDesc, PassThroughActivation
+    good = ConvLayerDesc(K=3, IFM_CH=4, IFM_DIM=9, OFM_CH=6, SIMD=2, PE=3).to_c(PassThroughActivation(16, True))
+    assert _lib.lib().sicn_convlayer_validate(ctypes.byref(good)) == 0
+    for field, val in (("K", 12), ("SIMD", 3), ("PE", 4), ("W_BIT", 9), ("ACC_BIT", 33), ("OUT_BIT", 12), ("OFM_DIM", 9),
+                       ("NUM_TH", 2), ("IN_BIT", 4)):
+        bad = ConvLayerDesc(K=3, IFM_CH=4, IFM_DIM=9, OFM_CH=6, SIMD=2, PE=3).to_c(PassThroughActivation(16, True))
+        setattr(bad, field, val)
+        assert _lib.lib().sicn_convlayer_validate(ctypes.byref(bad)) == -22, field
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_gpu_conv_layer_batch_matches_oracle(case):
+    import torch
+    from simple_image_compression_network_amd.api import FixedPointWeights
+    from simple_image_compression_network_amd.convlayer import (ConvLayer_Batch, ConvLayerDesc, PassThroughActivation,
+                                                                ThresholdsActivation)
+    rng = np.random.default_rng(abs(hash(case)) % (1 << 32))
+    K, C, D, O, SIMD, PE, WB, INS, AB, AS, OB, NTH, AV = case
+    d, _, words, x, thr, ref = _make(case, rng)
+    desc = ConvLayerDesc(K=K, IFM_CH=C, IFM_DIM=D, OFM_CH=O, SIMD=SIMD, PE=PE, W_BIT=WB, IN_SIGNED=bool(INS), OUT_BIT=OB)
+    act = ThresholdsActivation(thr, AB, bool(AS), AV) if NTH else PassThroughActivation(AB, bool(AS))
+    xin = torch.from_numpy(np.stack([x, x[::-1].copy()])).cuda()
+    out = ConvLayer_Batch(desc, xin, None, FixedPointWeights(SIMD, WB, PE, d.W_TILES, words), act, 2)
+    got = out.cpu().numpy().astype(np.int64) & ((1 << OB) - 1)
+    assert np.array_equal(got[0], ref.astype(np.int64))
+    ref1 = c_oracle.convlayer_dataflow(d, words, thr, x[::-1].copy(), use_fsm=False)
+    assert np.array_equal(got[1], ref1.astype(np.int64))
