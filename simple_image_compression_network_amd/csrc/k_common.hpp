@@ -82,11 +82,12 @@ __device__ __forceinline__ uint32_t tensor_offset(int layout, int y, int x, uint
 // (s*(Yb+ty)+ay, s*(Xb+tx)+ax).  The LDS image keeps logical half h of position p at physical
 // half h ^ ((p>>3)&1) (bank-conflict-free ds_read_b128).
 __device__ __forceinline__ uint32_t piece_src_offset(int k, int lane, int Yb, int Xb, int s, int ay, int ax,
-                                                     int IW, int IH, int layout, uint32_t g, int C)
+                                                     int IW, int IH, int layout, uint32_t g, int C, bool swizzle = true)
 {
     const int p = k * 32 + (lane >> 1);
     const int ty = p / PATCH_X, tx = p - ty * PATCH_X;
-    const int hlog = (lane & 1) ^ ((p >> 3) & 1);
+    // 32x32x32 fragments want half h of position p at h ^ ((p>>3)&1); 16x16x64 fragments want it plain
+    const int hlog = swizzle ? (lane & 1) ^ ((p >> 3) & 1) : (lane & 1);
     const int iy = s * (Yb + ty) + ay, ix = s * (Xb + tx) + ax;
     const bool ok = p < PATCH_PIX && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
     return ok ? tensor_offset(layout, iy, ix, g, C, IW, IH) + hlog * 16 : OOB;

@@ -1,0 +1,351 @@
+// conv2d<> / deconv522<> implicit GEMM on v_mfma_i32_16x16x64_i8 — same decomposition, LDS patch,
+// weight ring and layouts as k_mfma.hip (read its header first), different MFMA shape.
+//
+// Why: on this power-limited chip the 32x32x32 int8 MFMA loop tops out at ~2.93 POP/s and the
+// 16x16x64 loop at ~3.45 POP/s with identical LDS traffic per MAC (tools/microbench/mfma_shape.hip,
+// profiles/r01_microbench_mfma_shape.txt); k_mfma.hip already sits on the 32x32x32 ceiling.
+//
+// One "pass" = TWO K steps of k_mfma.hip (2 x 32 channel bytes = the 64-deep K of the instruction):
+// lanes 0..31 (K bytes 0..31 of the MFMA) read step A's operands, lanes 32..63 step B's.
+//   conv  : A, B = two consecutive taps of the plane-ordered walk (possibly two different planes)
+//   deconv: A, B = channel groups q, q+1 of the same tap
+// Lane roles (l = lane): pos/row = l & 15, g = l >> 4: step = g >> 1, 16-byte half = g & 1.
+//   pixel fragment c (4 per wave: row i = c >> 1 of the wave's two rows, x half c & 1):
+//       16 bytes at patch[sub_step][(2w + i + oy_step) * 34 + 16*(c&1) + pos + ox_step][half]
+//   weight fragment j (COUT/16 per pass): 16 bytes at ring[step][row j*16 + pos][half]
+// Neither image is swizzled: the hardware's 16-lane ds_read_b128 groups pair positions {0-3,12-15}
+// of one half with positions {4-11} of the other, which already covers 16 distinct 16-byte slots.
+// C/D layout (col = l & 15 = position, row = 4g + r): weight row (4g + r) of tile j holds channel
+// 64*(j>>2) + 16g + 4*(j&3) + r, so the four accumulators of tiles 4J..4J+3 of a lane are 16
+// consecutive channels of one pixel: one 16-byte store per (column tile, J), no transpose.
+// A barrier per pass (not per step) halves the barrier count of k_mfma.hip.
+#include <cstdlib>
+
+#include "k_common.hpp"
+
+namespace sicn {
+
+constexpr int PF16 = 4;    // weight tiles (K steps) in flight ahead of the consumer, even
+constexpr int RING16 = 6;  // >= PF16 + 2
+
+template <int TB>
+__device__ __forceinline__ void load_wtile16(uint8_t *ring, const int8_t *wstream, int tile, int lane, int w)
+{
+    constexpr int NPB = TB / 1024, WR = (NPB + 3) / 4;
+    const int8_t *src = wstream + (size_t)tile * TB + lane * 16;
+    uint8_t *dst = ring + (tile % RING16) * TB;
+#pragma unroll
+    for (int r = 0; r < WR; r++) {
+        int piece = r * 4 + w;
+        if (piece >= NPB) piece -= 2;  // NPB == 6: waves 2,3 re-load pieces 4,5 (same bytes)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src + piece * 1024), LDS_PTR(dst + piece * 1024), 16, 0, 0);
+    }
+}
+
+// accumulators start at the bias: register r of tile (c, j) is channel 64*(j>>2) + 16g + 4*(j&3) + r
+template <int NT16>
+__device__ __forceinline__ void init_acc16(v4i (&acc)[4][NT16], const int8_t *bias, int g)
+{
+#pragma unroll
+    for (int J = 0; J < NT16 / 4; J++) {
+        const v4i b4 = *(const v4i *)(bias + 64 * J + 16 * g);
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            v4i v;
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = (int)(int8_t)((uint32_t)b4[jj] >> (8 * r));
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c][4 * J + jj] = v;
+        }
+    }
+}
+
+// One pass: fragments of steps A (lanes 0..31) and B (lanes 32..63), then 4 * NT16 MFMAs, then the
+// counted wait + barrier that publishes the next pass's weight tiles.
+//   pix_off : byte offset of this lane's fragment 0 inside the patch, already including the step
+//             (sub-patch, tap offset) selected by the lane's K half
+//   wt_off  : byte offset of this lane's fragment 0 inside the ring, including the step's slot
+template <int NT16, int VMCNT, int EXTRA>
+__device__ __forceinline__ void pass16(v4i (&acc)[4][NT16], const uint8_t *patch, const uint8_t *ring, uint32_t pix_off,
+                                       uint32_t wt_off, bool extra)
+{
+    v4i pf[4], wf[NT16];
+#pragma unroll
+    for (int c = 0; c < 4; c++) pf[c] = *(const v4i *)(patch + pix_off + ((c >> 1) * PATCH_X + (c & 1) * 16) * 32);
+#pragma unroll
+    for (int j = 0; j < NT16; j++) wf[j] = *(const v4i *)(ring + wt_off + j * 16 * 32);
+#pragma unroll
+    for (int j = 0; j < NT16; j++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[c][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[j], pf[c], acc[c][j], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 + NT16, 0);   // all fragment reads first
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT16, 0);   // then the MFMA cluster
+    if (EXTRA > 0 && extra)
+        wait_vmcnt<VMCNT + EXTRA>();
+    else
+        wait_vmcnt<VMCNT>();
+    block_barrier();
+}
+
+template <int NT16>
+__device__ __forceinline__ void store_tiles16(const v4i (&acc)[4][NT16], uint8_t *out_img, int OW, int OH, int MW, int MH,
+                                              int Y0, int X0, int w, int pos, int g, bool deconv, int py, int px,
+                                              int out_layout)
+{
+    constexpr int COUT = NT16 * 16;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int gy = Y0 + 2 * w + (c >> 1), gx = X0 + (c & 1) * 16 + pos;
+        if (gy < MH && gx < MW) {
+            const int oy_ = deconv ? 2 * gy + py : gy, ox_ = deconv ? 2 * gx + px : gx;
+#pragma unroll
+            for (int J = 0; J < NT16 / 4; J++) {
+                uint4 v;
+                v.x = pack4_relu7(acc[c][4 * J + 0][0], acc[c][4 * J + 0][1], acc[c][4 * J + 0][2], acc[c][4 * J + 0][3]);
+                v.y = pack4_relu7(acc[c][4 * J + 1][0], acc[c][4 * J + 1][1], acc[c][4 * J + 1][2], acc[c][4 * J + 1][3]);
+                v.z = pack4_relu7(acc[c][4 * J + 2][0], acc[c][4 * J + 2][1], acc[c][4 * J + 2][2], acc[c][4 * J + 2][3]);
+                v.w = pack4_relu7(acc[c][4 * J + 3][0], acc[c][4 * J + 3][1], acc[c][4 * J + 3][2], acc[c][4 * J + 3][3]);
+                // channels 64J + 16g .. +15 = channel group 2J + (g>>1), second half iff g odd
+                const uint32_t off = tensor_offset(out_layout, oy_, ox_, (uint32_t)(2 * J + (g >> 1)), COUT, OW, OH) + 16 * (g & 1);
+                *(uint4 *)(out_img + off) = v;
+            }
+        }
+    }
+}
+
+// conv: refresh schedule of the 4 parity planes in a 25-step channel group.  A plane may only be
+// re-filled from the pass AFTER the one that holds its last read, whatever the step parity of the
+// group is, i.e. from (last read step + 2): plane 0 (last read 8) at steps 10..12, plane 1 (14) at
+// 16..18, plane 2 (20) at 22..24, plane 3 (24) at steps 1..3 of the NEXT group.
+__host__ __device__ constexpr int refresh16_plane(int t)
+{
+    return (t >= 1 && t < 4) ? 3 : (t >= 10 && t < 13) ? 0 : (t >= 16 && t < 19) ? 1 : (t >= 22 && t < 25) ? 2 : -1;
+}
+__host__ __device__ constexpr int refresh16_slot(int t) { return t < 4 ? t - 1 : t < 13 ? t - 10 : t < 19 ? t - 16 : t - 22; }
+
+struct Conv16Ctx {
+    uint8_t *patch;
+    uint8_t *ring;
+    const int8_t *wstream;
+    const uint8_t *in_img;
+    int in_img_bytes;
+    uint32_t lane_pix;   // ((2w) * 34 + pos) * 32 + half * 16
+    uint32_t lane_wt;    // pos * 32 + half * 16
+    int lane, w, hi;     // hi = this lane serves step B (lanes 32..63)
+};
+
+// pass P of a 50-step window (two channel groups q0, q0+1): steps 2P, 2P+1
+template <int NT16, int P>
+__device__ __forceinline__ void conv_passes16(v4i (&acc)[4][NT16], const Conv16Ctx &c, const uint32_t (&poff)[4][3], int q0,
+                                              uint32_t qstride)
+{
+    constexpr int TB = NT16 * 16 * KSTEP, WR = (TB / 1024 + 3) / 4;
+    constexpr int SA = 2 * P, SB = 2 * P + 1;              // steps inside the 50-step window
+    constexpr int TA = SA % 25, TBs = SB % 25;             // tap index inside the channel group
+    constexpr Tap tapA = conv_tap(TA), tapB = conv_tap(TBs);
+    constexpr int planeA = (tapA.ky & 1) * 2 + (tapA.kx & 1), planeB = (tapB.ky & 1) * 2 + (tapB.kx & 1);
+    constexpr uint32_t offA = planeA * SUB_ALLOC + ((tapA.ky >> 1) * PATCH_X + (tapA.kx >> 1)) * 32;
+    constexpr uint32_t offB = planeB * SUB_ALLOC + ((tapB.ky >> 1) * PATCH_X + (tapB.kx >> 1)) * 32;
+    const int qA = q0 + SA / 25, qB = q0 + SB / 25;
+    const int stepA = qA * 25 + TA, stepB = qB * 25 + TBs;   // = stepA + 1
+    // (1) plane refresh pieces scheduled for these two steps
+    constexpr int rpA = refresh16_plane(TA), rpB = refresh16_plane(TBs);
+    if constexpr (rpA >= 0) {
+        constexpr int slot = refresh16_slot(TA);
+        load_piece(c.patch, c.in_img, c.in_img_bytes, rpA, slot * 4 + c.w,
+                   poff[rpA][slot] + (uint32_t)((rpA == 3) ? qA : qA + 1) * qstride);
+    }
+    if constexpr (rpB >= 0) {
+        constexpr int slot = refresh16_slot(TBs);
+        load_piece(c.patch, c.in_img, c.in_img_bytes, rpB, slot * 4 + c.w,
+                   poff[rpB][slot] + (uint32_t)((rpB == 3) ? qB : qB + 1) * qstride);
+    }
+    // (2) weight tiles of the pass after next (the stream is padded with PF16 zero tiles)
+    load_wtile16<TB>(c.ring, c.wstream, stepA + PF16, c.lane, c.w);
+    load_wtile16<TB>(c.ring, c.wstream, stepB + PF16, c.lane, c.w);
+    // (3) MFMAs; the wait leaves exactly this pass's own loads in flight
+    const uint32_t pix = c.lane_pix + (c.hi ? offB : offA);
+    const uint32_t wt = c.lane_wt + (uint32_t)(((c.hi ? stepB : stepA) % RING16) * TB);
+    pass16<NT16, 2 * WR + (rpA >= 0) + (rpB >= 0), 0>(acc, c.patch, c.ring, pix, wt, false);
+    if constexpr (P + 1 < 25) conv_passes16<NT16, P + 1>(acc, c, poff, q0, qstride);
+}
+
+template <int NQ, int NT16, bool DECONV, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_mfma16_t(
+    const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int8_t *__restrict__ wstream,
+    const int8_t *__restrict__ bias, int IW, int IH, int OW, int OH, int MW, int MH, int tiles_x, int in_layout,
+    int out_layout)
+{
+    static_assert(NQ % 2 == 0, "channel groups are consumed in pairs");
+    constexpr int CIN = NQ * 32, COUT = NT16 * 16;
+    constexpr int NSUB = DECONV ? NQ : 4;
+    constexpr int TB = COUT * KSTEP, WR = (TB / 1024 + 3) / 4;
+
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *patch = smem;
+    uint8_t *ring = smem + NSUB * SUB_ALLOC;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pos = lane & 15, g = lane >> 4, hi = g >> 1, half = g & 1;
+    const int img = blockIdx.z;
+    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+    const int Y0 = tile_y * TILE_Y, X0 = tile_x * TILE_X;
+
+    const int in_img_bytes = IH * IW * CIN;
+    const uint8_t *in_img = in + (size_t)img * in_img_bytes;
+    uint8_t *out_img = out + (size_t)img * OH * OW * COUT;
+    const uint32_t lane_pix = (uint32_t)(((2 * w) * PATCH_X + pos) * 32 + half * 16);
+    const uint32_t lane_wt = (uint32_t)(pos * 32 + half * 16);
+
+    v4i acc[4][NT16];
+
+    if constexpr (DECONV) {
+        // ---- prologue: the whole patch (NQ channel groups) + PF16 weight tiles -------------------
+#pragma unroll
+        for (int sub = 0; sub < NQ; sub++)
+#pragma unroll
+            for (int slot = 0; slot < 3; slot++)
+                load_piece(patch, in_img, in_img_bytes, sub, slot * 4 + w,
+                           piece_src_offset(slot * 4 + w, lane, Y0 - 1, X0 - 1, 1, 0, 0, IW, IH, in_layout, (uint32_t)sub, CIN,
+                                            false));
+#pragma unroll
+        for (int s = 0; s < PF16; s++) load_wtile16<TB>(ring, wstream, s, lane, w);
+        wait_vmcnt<0>();
+        block_barrier();
+
+        int step = 0;
+#pragma unroll
+        for (int ph = 0; ph < 4; ph++) {
+            const int py = ph >> 1, px = ph & 1;
+            const int nkx = 3 - px, ntap = (3 - py) * nkx;
+            init_acc16<NT16>(acc, bias, g);
+#pragma unroll 1
+            for (int t = 0; t < ntap; t++) {
+                const int iy = t / nkx, ix = t - iy * nkx;
+                const uint32_t tap_off = (uint32_t)(((iy + py) * PATCH_X + ix + px) * 32);
+#pragma unroll
+                for (int q = 0; q < NQ; q += 2) {
+                    load_wtile16<TB>(ring, wstream, step + q + PF16, lane, w);
+                    load_wtile16<TB>(ring, wstream, step + q + 1 + PF16, lane, w);
+                    const uint32_t pix = lane_pix + tap_off + (uint32_t)((q + hi) * SUB_ALLOC);
+                    const uint32_t wt = lane_wt + (uint32_t)(((step + q + hi) % RING16) * TB);
+                    // first pass of a phase: the previous phase's 2*NT16/4 stores are younger than the
+                    // awaited tiles — count them instead of waiting for them
+                    pass16<NT16, 2 * WR, NT16>(acc, patch, ring, pix, wt, ph > 0 && t == 0 && q == 0);
+                }
+                step += NQ;
+            }
+            if (ph == 3) wait_vmcnt<0>();  // the padded tail of the weight prefetch must land before exit
+            store_tiles16<NT16>(acc, out_img, OW, OH, MW, MH, Y0, X0, w, pos, g, true, py, px, out_layout);
+        }
+    } else {
+        // ---- per-lane source offsets of the 4 planes x 3 refresh slots (channel group 0) --------
+        uint32_t poff[4][3];
+#pragma unroll
+        for (int pl = 0; pl < 4; pl++)
+#pragma unroll
+            for (int slot = 0; slot < 3; slot++)
+                poff[pl][slot] = piece_src_offset(slot * 4 + w, lane, Y0 - 1, X0 - 1, 2, pl >> 1, pl & 1, IW, IH, in_layout, 0u,
+                                                  CIN, false);
+        const uint32_t qstride = in_layout == LAYOUT_GROUP ? (uint32_t)(IW * IH * 32) : 32u;   // conv: NHWC or GROUP
+        // ---- prologue: planes 0..2 of group 0 (plane 3 arrives in steps 1..3) + PF16 weight tiles -
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+            for (int slot = 0; slot < 3; slot++) load_piece(patch, in_img, in_img_bytes, pl, slot * 4 + w, poff[pl][slot]);
+#pragma unroll
+        for (int s = 0; s < PF16; s++) load_wtile16<TB>(ring, wstream, s, lane, w);
+        wait_vmcnt<0>();
+        block_barrier();
+
+        const Conv16Ctx ctx{patch, ring, wstream, in_img, in_img_bytes, lane_pix, lane_wt, lane, w, hi};
+        init_acc16<NT16>(acc, bias, g);
+#pragma unroll 1
+        for (int q0 = 0; q0 < NQ; q0 += 2) conv_passes16<NT16, 0>(acc, ctx, poff, q0, qstride);
+        wait_vmcnt<0>();
+        store_tiles16<NT16>(acc, out_img, OW, OH, MW, MH, Y0, X0, w, pos, g, false, 0, 0, out_layout);
+    }
+}
+
+#define SICN_INST16(NQ, NT16, D)                                                                                 \
+    template __global__ void k_mfma16_t<NQ, NT16, D, ((NT16 <= 8 && NQ <= 4) ? 2 : 1)>(                           \
+        const uint8_t *__restrict__, uint8_t *__restrict__, const int8_t *__restrict__, const int8_t *__restrict__, \
+        int, int, int, int, int, int, int, int, int);
+SICN_INST16(4, 8, true)
+SICN_INST16(4, 8, false)
+SICN_INST16(4, 12, false)
+#undef SICN_INST16
+
+template <int NQ, int NT16, bool DECONV>
+static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
+                           hipStream_t stream, int in_layout, int out_layout)
+{
+    constexpr int NSUB = DECONV ? NQ : 4;
+    constexpr int MINW = ((NT16 <= 8 && NQ <= 4) ? 2 : 1);
+    const int MW = DECONV ? g.IW : g.OW, MH = DECONV ? g.IH : g.OH;
+    const int tiles_x = (MW + TILE_X - 1) / TILE_X, tiles_y = (MH + TILE_Y - 1) / TILE_Y;
+    const size_t lds = (size_t)NSUB * SUB_ALLOC + (size_t)RING16 * NT16 * 16 * KSTEP;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mfma16_t<NQ, NT16, DECONV, MINW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    dim3 grid((unsigned)(tiles_x * tiles_y), 1, (unsigned)n_images);
+    hipLaunchKernelGGL((k_mfma16_t<NQ, NT16, DECONV, MINW>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias,
+                       g.IW, g.IH, g.OW, g.OH, MW, MH, tiles_x, in_layout, out_layout);
+    return hipGetLastError();
+}
+
+hipError_t launch_mfma16(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
+                         hipStream_t stream, int in_layout, int out_layout)
+{
+    if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB) return hipErrorInvalidValue;          // 31-bit patch offsets
+    if ((size_t)g.OH * g.OW * g.COUT >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // 32-bit store offsets
+    if (g.transposed) {
+        if (g.CIN == 128 && g.COUT == 128) return launch16<4, 8, true>(g, w, in, out, n_images, stream, in_layout, out_layout);
+    } else {
+        if (g.CIN == 128 && g.COUT == 128) return launch16<4, 8, false>(g, w, in, out, n_images, stream, in_layout, out_layout);
+        if (g.CIN == 128 && g.COUT == 192) return launch16<4, 12, false>(g, w, in, out, n_images, stream, in_layout, out_layout);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---- host-side weight packing: the same tile sequence as pack_mfma_stream, rows in the 16x16 C/D
+// ---- order (LDS row j*16 + rho holds channel 64*(j>>2) + 16*(rho>>2) + 4*(j&3) + (rho&3)), no swizzle
+size_t mfma16_stream_bytes(int cin, int cout) { return (size_t)(25 * (cin / 32) + PF16) * cout * KSTEP; }
+
+static void pack_tile16(const int8_t *w_okc, int cin, int cout, int tap, int q, int8_t *tile)
+{
+    const int kk = 25 * cin;
+    for (int row = 0; row < cout; row++) {
+        const int j = row >> 4, rho = row & 15;
+        const int ch = 64 * (j >> 2) + 16 * (rho >> 2) + 4 * (j & 3) + (rho & 3);
+        const int8_t *src = w_okc + (size_t)ch * kk + tap * cin + q * 32;
+        for (int b = 0; b < 32; b++) tile[row * 32 + b] = src[b];
+    }
+}
+
+void pack_mfma16_stream(const int8_t *w_okc, int cin, int cout, int transposed, int8_t *dst)
+{
+    const int nq = cin / 32;
+    const size_t tb = (size_t)cout * KSTEP;
+    size_t step = 0;
+    if (!transposed) {
+        for (int q = 0; q < nq; q++)
+            for (int t = 0; t < 25; t++) {
+                const Tap tap = conv_tap(t);
+                pack_tile16(w_okc, cin, cout, tap.ky * 5 + tap.kx, q, dst + (step++) * tb);
+            }
+    } else {
+        for (int ph = 0; ph < 4; ph++) {
+            const int py = ph >> 1, px = ph & 1;
+            for (int iy = 0; iy < 3 - py; iy++)
+                for (int ix = 0; ix < 3 - px; ix++) {
+                    const int ky = 2 * iy + py, kx = 2 * ix + px;
+                    for (int q = 0; q < nq; q++) pack_tile16(w_okc, cin, cout, ky * 5 + kx, q, dst + (step++) * tb);
+                }
+        }
+    }
+    for (size_t i = step * tb; i < (step + PF16) * tb; i++) dst[i] = 0;
+}
+
+}  // namespace sicn

@@ -93,6 +93,7 @@ extern "C" void sicn_weights_free(sicn_weights *w)
     if (w->d_w_okc) (void)hipFree(w->d_w_okc);
     if (w->d_bias) (void)hipFree(w->d_bias);
     if (w->d_w_mfma) (void)hipFree(w->d_w_mfma);
+    if (w->d_w_mfma16) (void)hipFree(w->d_w_mfma16);
     if (w->d_w_l0) (void)hipFree(w->d_w_l0);
     if (w->d_w_l7) (void)hipFree(w->d_w_l7);
     delete w;
@@ -149,6 +150,11 @@ extern "C" int sicn_weights_from_finn_tiles(const sicn_layer_desc *d, const void
             pack_mfma_stream(w_okc.data(), cin, cout, d->transposed, s.data());
             w->mfma_steps = mfma_stream_steps(cin);
             ok = upload(s.data(), s.size(), &w->d_w_mfma);
+            if (ok) {
+                std::vector<int8_t> s16(mfma16_stream_bytes(cin, cout));
+                pack_mfma16_stream(w_okc.data(), cin, cout, d->transposed, s16.data());
+                ok = upload(s16.data(), s16.size(), &w->d_w_mfma16);
+            }
         }
         if (ok && !d->transposed && cin == 3 && cout % 32 == 0) {
             std::vector<int8_t> s(l0_bytes(cout));
@@ -202,7 +208,16 @@ static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint
     case KK_L0_RGB: e = launch_l0(g, *w, in, out, n_images, stream, out_layout); break;
     case KK_L7_RGB: e = launch_l7(g, *w, in, out, n_images, stream, in_layout); break;
     case KK_MFMA_CONV:
-    case KK_MFMA_DECONV: e = launch_mfma(g, *w, in, out, n_images, stream, in_layout, out_layout); break;
+    case KK_MFMA_DECONV: {
+        // MFMA shape: 16x16x64 by default (higher sustained clock, k_mfma16.hip); SICN_MFMA_SHAPE=32 selects
+        // the 32x32x32 kernels of k_mfma.hip (read per launch so both can be compared in one process)
+        const char *shape = getenv("SICN_MFMA_SHAPE");
+        // (the 192-input-channel deconv, layer 4, stays on the 32x32x32 kernel: its 16x16x64 variant spills)
+        e = ((shape && shape[0] == '3') || g.CIN != 128)
+                ? launch_mfma(g, *w, in, out, n_images, stream, in_layout, out_layout)
+                : launch_mfma16(g, *w, in, out, n_images, stream, in_layout, out_layout);
+        break;
+    }
     default: e = launch_generic(g, *w, in, out, n_images, stream); break;
     }
     if (e == hipErrorInvalidValue) return SICN_EINVAL;

@@ -41,6 +41,7 @@ struct sicn_weights {
     // 16-byte halves of a row swapped where the LDS swizzle wants it.
     int8_t *d_w_mfma;
     int mfma_steps;
+    int8_t *d_w_mfma16;    // the same tile sequence laid out for v_mfma_i32_16x16x64_i8 (k_mfma16.hip)
     int8_t *d_bias_sigma;  // [cout] bias in sigma order == natural order (kept for clarity)
     // layer-0 (RGB -> cout) and layer-7 (cin -> RGB) layouts, or nullptr
     int8_t *d_w_l0;
@@ -57,6 +58,8 @@ hipError_t launch_generic(const LayerGeom &g, const sicn_weights &w, const uint8
 // in_layout / out_layout: LAYOUT_NHWC (the ABI layout) / LAYOUT_GROUP / LAYOUT_PHASE (k_common.hpp)
 hipError_t launch_mfma(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
                        int n_images, hipStream_t stream, int in_layout, int out_layout);
+hipError_t launch_mfma16(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
+                         int n_images, hipStream_t stream, int in_layout, int out_layout);
 hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
                      int n_images, hipStream_t stream, int out_layout);
 hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
@@ -68,6 +71,8 @@ size_t mfma_stream_bytes(int cin, int cout);
 int mfma_stream_steps(int cin);
 void pack_mfma_stream(const int8_t *w_okc, int cin, int cout, int transposed, int8_t *dst);
 bool mfma_supported(int cin, int cout, int transposed);
+size_t mfma16_stream_bytes(int cin, int cout);
+void pack_mfma16_stream(const int8_t *w_okc, int cin, int cout, int transposed, int8_t *dst);
 
 size_t l0_bytes(int cout);
 void pack_l0(const int8_t *w_okc, int cout, int8_t *dst);
