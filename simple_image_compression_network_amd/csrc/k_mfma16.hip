@@ -25,8 +25,14 @@
 
 namespace sicn {
 
-constexpr int PF16 = 4;    // weight tiles (K steps) in flight ahead of the consumer, even
-constexpr int RING16 = 6;  // >= PF16 + 2
+#ifndef SICN_PF16
+#define SICN_PF16 6
+#endif
+#ifndef SICN_RING16
+#define SICN_RING16 8
+#endif
+constexpr int PF16 = SICN_PF16;      // weight tiles (K steps) in flight ahead of the consumer, even
+constexpr int RING16 = SICN_RING16;  // >= PF16 + 2
 
 template <int TB>
 __device__ __forceinline__ void load_wtile16(uint8_t *ring, const int8_t *wstream, int tile, int lane, int w)
@@ -78,8 +84,10 @@ __device__ __forceinline__ void pass16(v4i (&acc)[4][NT16], const uint8_t *patch
     for (int j = 0; j < NT16; j++)
 #pragma unroll
         for (int c = 0; c < 4; c++) acc[c][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[j], pf[c], acc[c][j], 0, 0, 0);
+#ifndef SICN_NO_SCHED16
     __builtin_amdgcn_sched_group_barrier(0x100, 4 + NT16, 0);   // all fragment reads first
     __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT16, 0);   // then the MFMA cluster
+#endif
     if (EXTRA > 0 && extra)
         wait_vmcnt<VMCNT + EXTRA>();
     else
