@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
             for (int t = 0; t < ntap; t++) {
                 const int iy = t / nkx, ix = t - iy * nkx;
                 const uint32_t tap_off = (uint32_t)(((iy + py) * PATCH_X + ix + px) * 32);
-#pragma unroll
+#pragma unroll NQ <= 4 ? 2 : 1
                 for (int q = 0; q < NQ; q += 2) {
                     load_wtile16<TB>(ring, wstream, step + q + PF16, lane, w);
                     load_wtile16<TB>(ring, wstream, step + q + 1 + PF16, lane, w);
@@ -281,6 +281,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
         const uint8_t *__restrict__, uint8_t *__restrict__, const int8_t *__restrict__, const int8_t *__restrict__, \
         int, int, int, int, int, int, int, int, int);
 SICN_INST16(4, 8, true)
+SICN_INST16(6, 8, true)
 SICN_INST16(4, 8, false)
 SICN_INST16(4, 12, false)
 #undef SICN_INST16
@@ -310,6 +311,7 @@ hipError_t launch_mfma16(const LayerGeom &g, const sicn_weights &w, const uint8_
     if ((size_t)g.OH * g.OW * g.COUT >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // 32-bit store offsets
     if (g.transposed) {
         if (g.CIN == 128 && g.COUT == 128) return launch16<4, 8, true>(g, w, in, out, n_images, stream, in_layout, out_layout);
+        if (g.CIN == 192 && g.COUT == 128) return launch16<6, 8, true>(g, w, in, out, n_images, stream, in_layout, out_layout);
     } else {
         if (g.CIN == 128 && g.COUT == 128) return launch16<4, 8, false>(g, w, in, out, n_images, stream, in_layout, out_layout);
         if (g.CIN == 128 && g.COUT == 192) return launch16<4, 12, false>(g, w, in, out, n_images, stream, in_layout, out_layout);

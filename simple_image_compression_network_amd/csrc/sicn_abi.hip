@@ -212,8 +212,7 @@ static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint
         // MFMA shape: 16x16x64 by default (higher sustained clock, k_mfma16.hip); SICN_MFMA_SHAPE=32 selects
         // the 32x32x32 kernels of k_mfma.hip (read per launch so both can be compared in one process)
         const char *shape = getenv("SICN_MFMA_SHAPE");
-        // (the 192-input-channel deconv, layer 4, stays on the 32x32x32 kernel: its 16x16x64 variant spills)
-        e = ((shape && shape[0] == '3') || g.CIN != 128)
+        e = (shape && shape[0] == '3')
                 ? launch_mfma(g, *w, in, out, n_images, stream, in_layout, out_layout)
                 : launch_mfma16(g, *w, in, out, n_images, stream, in_layout, out_layout);
         break;
