@@ -76,6 +76,24 @@ __device__ __forceinline__ uint32_t tensor_offset(int layout, int y, int x, uint
     return (plane * hw + (uint32_t)((y >> 1) * (W >> 1) + (x >> 1))) * 32u;
 }
 
+// The same three layouts as strides (wave-uniform), for kernels that compute many offsets per step:
+//   offset = ((y>>sh)*row + (x>>sh))*pix + g*grp + ((y&sh)*2 + (x&sh))*ph          (no branches)
+struct TensorMap {
+    uint32_t sh, row, pix, grp, ph;
+};
+__device__ __forceinline__ TensorMap tensor_map(int layout, int C, int W, int H)
+{
+    if (layout == LAYOUT_NHWC) return TensorMap{0u, (uint32_t)W, (uint32_t)C, 32u, 0u};
+    if (layout == LAYOUT_GROUP) return TensorMap{0u, (uint32_t)W, 32u, (uint32_t)(W * H) * 32u, 0u};
+    const uint32_t hw = (uint32_t)((W >> 1) * (H >> 1));
+    return TensorMap{1u, (uint32_t)(W >> 1), 32u, hw * 32u, (uint32_t)(C >> 5) * hw * 32u};
+}
+__device__ __forceinline__ uint32_t tensor_offset(const TensorMap &t, int y, int x, uint32_t g)
+{
+    return (((uint32_t)y >> t.sh) * t.row + ((uint32_t)x >> t.sh)) * t.pix + g * t.grp +
+           (((uint32_t)y & t.sh) * 2u + ((uint32_t)x & t.sh)) * t.ph;
+}
+
 // Source offset (bytes from the image base) of this lane's 16 bytes of LDS-DMA piece `k` of a
 // sub-patch: position p = k*32 + lane/2 of the (TILE_Y+2) x (TILE_X+2) window whose origin is
 // (Yb, Xb) in "patch coordinates"; patch coordinate (ty,tx) maps to input pixel

@@ -7,6 +7,8 @@
 //          reads IFM_CH B/pixel (the bound), writes 4 x 3 B per input position.
 //
 // Both follow the closed forms of SURVEY.md §8(a) a8/a9 (bit-exact, wrap mod 256, relu7).
+#include <cstdlib>
+
 #include "k_common.hpp"
 
 namespace sicn {
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, u
                 acc[1][j][r] = bv;
             }
         }
+#ifndef SICN_EXP_L0_NO_MFMA   // experiment builds only (tools/ab_libs.sh)
 #pragma unroll
         for (int ky = 0; ky < 5; ky++) {
             v4i wf[NTJ], pf[2];
@@ -154,6 +157,7 @@ __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, u
                 for (int i = 0; i < 2; i++)
                     acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[j], pf[i], acc[i][j], 0, 0, 0);
         }
+#endif
         if (more) {  // write late: into the patch nobody reads during this iteration
             wait_vmcnt<0>();
             uint8_t *nxt = patch0 + (buf ^ 1) * L0_PATCH;
@@ -172,12 +176,24 @@ __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, u
                     v.y = pack4_relu7(a[4], a[5], a[6], a[7]);
                     v.z = pack4_relu7(a[8], a[9], a[10], a[11]);
                     v.w = pack4_relu7(a[12], a[13], a[14], a[15]);
+#ifdef SICN_EXP_L0_NO_STORE
+                    if (v.x != 0xffffffffu) continue;   // never true after relu7, the compiler cannot know
+#endif
                     *(uint4 *)(out_img + tensor_offset(out_layout, gy, gx, (uint32_t)j, COUT, OW, OH) + 16 * kh) = v;
                 }
             }
         }
         block_barrier();  // next patch complete, this patch free (raw barrier: stores stay in flight)
     }
+}
+
+// Test hook: SICN_STRIP_CHUNKS=n forces the number of vertical chunks a strip is cut into (the
+// default heuristic gives small images one step per workgroup, which never exercises the rolling
+// window); read per launch.
+static int strip_chunks_override()
+{
+    const char *e = getenv("SICN_STRIP_CHUNKS");
+    return (e && *e) ? atoi(e) : 0;
 }
 
 size_t l0_bytes(int cout) { return (size_t)5 * cout * KSTEP; }
@@ -204,7 +220,8 @@ hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
                      int n_images, hipStream_t stream, int out_layout)
 {
     const int tiles_x = (g.OW + TILE_X - 1) / TILE_X, tiles_y = (g.OH + TILE_Y - 1) / TILE_Y;
-    int y_chunks = (4096 + tiles_x * n_images - 1) / (tiles_x * n_images);
+    int y_chunks = strip_chunks_override();
+    if (y_chunks <= 0) y_chunks = (4096 + tiles_x * n_images - 1) / (tiles_x * n_images);
     y_chunks = y_chunks < 1 ? 1 : (y_chunks > tiles_y ? tiles_y : y_chunks);
     dim3 grid((unsigned)tiles_x, (unsigned)y_chunks, (unsigned)n_images);
     if ((size_t)g.IH * g.IW * 3 * (size_t)n_images + 4 >= (size_t)OOB) return hipErrorInvalidValue;
@@ -226,19 +243,61 @@ hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
 // (9 taps x two 64-channel halves).  Output tile: lane (position l&15, phase l>>4) holds the 3
 // channel bytes of out[2y+py][2x+px].
 //   * W' (18 KB) is held in REGISTERS (72 VGPRs) for the whole vertical strip a workgroup walks.
-//   * LDS patch: two regions (K-group parity kg&1), each [position][4 chunks x 16 B] with chunk
-//     c2 = 2*half + (kg>>1) stored at c2 ^ ((p>>2)&3): a 16-lane ds_read_b128 group covers 16
-//     distinct positions at ONE c2, i.e. 16 distinct 16-byte slots of a 256-byte LDS row.
-//   * RGB output is transposed through a 768-byte per-wave LDS staging tile and stored as dwords.
+//   * The strip is walked in steps of 4 input rows (wave w = row w, 32 positions).  The input
+//     lives in a ROLLING LDS window: position P = r*36 + tx (r = row counted from the top of the
+//     strip, 34 of the 36 columns used) sits at ring slot P mod 368.  One step needs rows
+//     4t+2..4t+7 and, while it computes, the 4 rows of the next step (exactly 9 pieces of 16
+//     positions per region) are fetched by LDS-DMA into the slots the previous step freed: every
+//     input row is fetched once per strip (fetch = 34/32 of the input) and the load latency is
+//     hidden behind a whole step.  One barrier per step.
+//   * Two LDS regions (K-group parity kg&1), each [slot][4 chunks x 16 B] with chunk
+//     c2 = 2*half + (kg>>1) stored at c2 ^ ((P>>2)&3): a 16-lane ds_read_b128 group covers 16
+//     distinct positions at ONE c2, i.e. 16 distinct 16-byte slots of a 256-byte LDS row.  Ring
+//     wrap and step advance are multiples of 16 positions, so the XOR term is a lane constant.
+//   * RGB output is transposed through a 384-byte per-wave LDS staging tile and stored as dwords
+//     through a buffer descriptor (masked lanes = out of range), so a step always issues exactly
+//     two stores and the wait for the prefetched rows is a counted vmcnt that leaves them in flight.
 // =============================================================================================
-constexpr int L7_REGION_PIECES = 22;                    // 340 positions x 64 B = 21760 B
-constexpr int L7_REGION = L7_REGION_PIECES * 1024;
-constexpr int L7_STAGE = 4 * 192;                       // 4 output rows x 64 pixels x 3 B per wave
+constexpr int L7_PITCH = 36;                             // positions per window row (34 used)
+constexpr int L7_ROWS = 4;                               // input rows per step
+constexpr int L7_STEP_PIECES = L7_ROWS * L7_PITCH / 16;  // 9 LDS-DMA pieces per region per step
+constexpr int L7_RING_PIECES = 23;                       // 368 positions >= 10 rows x 36
+constexpr int L7_RING_POS = L7_RING_PIECES * 16;
+constexpr int L7_REGION = L7_RING_PIECES * 1024;
+constexpr int L7_STAGE = 2 * 192;                        // 2 output rows x 64 pixels x 3 B per wave
+static_assert(L7_ROWS * L7_PITCH % 16 == 0 && L7_RING_POS >= (L7_ROWS + 6) * L7_PITCH, "ring geometry");
 
-__global__ __launch_bounds__(256, 2) void k_l7(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+// LDS-DMA pieces `first + 4i` (i < n) of a run of window rows: piece j < npieces covers region
+// j / per_region, positions (j % per_region)*16 .. +15 of the run; row 0 of the run is input row iy0
+// and lands at ring piece slot pslot0.  Rows before `iy_min` (>= 0) are not fetched (zero fill).
+template <int N>
+__device__ __forceinline__ void l7_load_rows(uint8_t *patch, const uint8_t *in_img, int in_img_bytes, int w, int lane,
+                                             int per_region, int iy0, int iy_min, int pslot0, int X0, int IW, int IH,
+                                             const TensorMap &tm)
+{
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)in_img, 0, in_img_bytes, 0x00020000);
+    const int c2 = (lane & 3) ^ ((lane >> 4) & 3);   // stored chunk (lane&3) of position P holds c2 ^ ((P>>2)&3)
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int j = w + 4 * i;
+        if (j < 2 * per_region) {   // wave-uniform
+            const int region = j >= per_region ? 1 : 0, kk = j - region * per_region;
+            const int q = kk * 16 + (lane >> 2);
+            const int row = q / L7_PITCH, tx = q - row * L7_PITCH;
+            const int iy = iy0 + row, ix = X0 - 1 + tx;
+            const bool ok = tx < TILE_X + 2 && iy >= iy_min && iy < IH && ix >= 0 && ix < IW;
+            const uint32_t off = ok ? tensor_offset(tm, iy, ix, (uint32_t)c2) + 16u * region : OOB;
+            int slot = pslot0 + kk;
+            slot = slot >= L7_RING_PIECES ? slot - L7_RING_PIECES : slot;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(patch + region * L7_REGION + slot * 1024), 16, off, 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void k_l7(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                const int8_t *__restrict__ w_l7,
                                                const int8_t *__restrict__ bias, int IW, int IH, int OW,
-                                               int OH, int tiles_y, int y_chunks, int in_layout)
+                                               int OH, int steps_y, int y_chunks, int in_layout)
 {
     constexpr int CIN = 128;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -249,9 +308,9 @@ __global__ __launch_bounds__(256, 2) void k_l7(const uint8_t *__restrict__ in, u
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int img = blockIdx.z;
     const int X0 = blockIdx.x * TILE_X;
-    const int ty_per = (tiles_y + y_chunks - 1) / y_chunks;
-    const int ty_begin = blockIdx.y * ty_per, ty_end = min(tiles_y, ty_begin + ty_per);
-    if (ty_begin >= ty_end) return;
+    const int per = (steps_y + y_chunks - 1) / y_chunks;
+    const int s_begin = blockIdx.y * per, s_end = min(steps_y, s_begin + per);
+    if (s_begin >= s_end) return;  // before any LDS-DMA is issued
 
     // lane roles in v_mfma_i32_16x16x64_i8: A row / B column = lane & 15, K bytes 16*(lane>>4)..+15
     const int m = lane & 15, kg = lane >> 4;
@@ -267,89 +326,91 @@ __global__ __launch_bounds__(256, 2) void k_l7(const uint8_t *__restrict__ in, u
     uint8_t *my_stage = stage + w * L7_STAGE;
     const bool fast_rows = ((OW * 3) & 3) == 0 && X0 + TILE_X <= IW;
 
-    for (int tile_y = ty_begin; tile_y < ty_end; tile_y++) {
-        const int Y0 = tile_y * TILE_Y;
-        block_barrier();  // every wave is done reading the previous patch
-        {
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)in_img, 0, in_img_bytes, 0x00020000);
-#pragma unroll
-            for (int r = 0; r < 2 * L7_REGION_PIECES / 4; r++) {
-                const int piece = r * 4 + w;                    // 44 pieces, 11 per wave
-                const int region = piece / L7_REGION_PIECES, k = piece - region * L7_REGION_PIECES;
-                const int p = k * 16 + (lane >> 2);
-                const int ty = p / PATCH_X, tx = p - ty * PATCH_X;
-                const int c2 = (lane & 3) ^ ((p >> 2) & 3);     // channel group of 32 = 2*half + (kg>>1)
-                const int iy = Y0 - 1 + ty, ix = X0 - 1 + tx;
-                const bool ok = p < PATCH_PIX && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
-                const uint32_t off = ok ? tensor_offset(in_layout, iy, ix, (uint32_t)c2, CIN, IW, IH) + 16u * region : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(patch + piece * 1024), 16, off, 0, 0, 0);
-            }
-        }
-        wait_vmcnt<0>();
-        block_barrier();
+    // window row r <-> input row 4*s_begin - 3 + r; rows 0,1 are never read (they only make the
+    // prologue a whole number of pieces)
+    const int iy_top = 4 * s_begin - 3;
+    const TensorMap tm = tensor_map(in_layout, CIN, IW, IH);
+    l7_load_rows<9>(patch, in_img, in_img_bytes, w, lane, 2 * L7_STEP_PIECES, iy_top, max(iy_top + 2, 0), 0, X0, IW, IH, tm);
 
-        // wave w owns rows 2w, 2w+1; each row = two 16-position column tiles
-        v4i acc[2][2];
+    // per-lane fragment addressing: P = (4t + 2 + w + dy)*36 + 16c + m + dx
+    uint32_t fa[9], fs[9];
 #pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int c = 0; c < 2; c++) acc[i][c] = v4i{b0, b1, b2, 0};  // C row 4*kg + r = phase kg, channel r
-        const uint8_t *reg = patch + (kg & 1) * L7_REGION;
+    for (int tap = 0; tap < 9; tap++) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const uint32_t a = (uint32_t)((2 + w + dy) * L7_PITCH + m + dx);
+        fa[tap] = a;
+        fs[tap] = (uint32_t)((kg & 1) * L7_REGION) + ((((uint32_t)(kg >> 1)) ^ ((a >> 2) & 3u)) << 4);
+    }
+    wait_vmcnt<0>();
+    block_barrier();
+
+    int base = 0;                          // (144 t) mod 368: ring slot of window row 4t, column 0
+    int pnext = 2 * L7_STEP_PIECES;        // (9t + 18) mod 23: ring piece slot of window row 4t + 8
+    for (int s = s_begin; s < s_end; s++) {
+        const int Y = 4 * s;               // first input row of this step
+        if (s + 1 < s_end)
+            l7_load_rows<5>(patch, in_img, in_img_bytes, w, lane, L7_STEP_PIECES, Y + 5, 0, pnext, X0, IW, IH, tm);
+
+        v4i acc[2];
+        acc[0] = acc[1] = v4i{b0, b1, b2, 0};  // C row 4*kg + r = phase kg, channel r
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
-            const int dy = tap / 3, dx = tap - dy * 3;
 #pragma unroll
-            for (int half = 0; half < 2; half++) {
-                const int c2 = 2 * half + (kg >> 1);
-#pragma unroll
-                for (int i = 0; i < 2; i++)
-#pragma unroll
-                    for (int c = 0; c < 2; c++) {
-                        const int p = (2 * w + i + dy) * PATCH_X + 16 * c + m + dx;
-                        const v4i pf = *(const v4i *)(reg + p * 64 + ((c2 ^ ((p >> 2) & 3)) << 4));
-                        acc[i][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[tap * 2 + half], pf, acc[i][c], 0, 0, 0);
-                    }
+            for (int c = 0; c < 2; c++) {
+                uint32_t slot = (uint32_t)base + fa[tap] + 16u * c;
+                slot = min(slot, slot - (uint32_t)L7_RING_POS);   // one wrap at most
+                const uint32_t addr = slot * 64u + fs[tap];
+#ifndef SICN_EXP_L7_NO_MFMA
+                const v4i p0 = *(const v4i *)(patch + addr);
+                const v4i p1 = *(const v4i *)(patch + (addr ^ 32u));   // channels 64..127: c2 ^ 2
+                acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[tap * 2 + 0], p0, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[tap * 2 + 1], p1, acc[c], 0, 0, 0);
+#endif
             }
         }
         // ---- epilogue ----------------------------------------------------------------------
+        const int gy = Y + w;
         if (fast_rows) {
-            // stage [4 rows = 2i+py][64 pixels = 2*(16c+m)+px][3] and write rows as dwords
+            // stage [2 rows = py][64 pixels = 2*(16c+m)+px][3] and write the rows as dwords
 #pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    const uint32_t v = pack4_relu7(acc[i][c][0], acc[i][c][1], acc[i][c][2], 0);
-                    uint8_t *d = my_stage + (2 * i + py) * 192 + (2 * (16 * c + m) + px) * 3;
-                    d[0] = (uint8_t)v;
-                    d[1] = (uint8_t)(v >> 8);
-                    d[2] = (uint8_t)(v >> 16);
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private staging: no barrier needed
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int idx = k * 64 + lane;                   // dword index in the 4 x 48 tile
-                const int row = idx / 48, col = idx - row * 48;
-                const int gy = Y0 + 2 * w + (row >> 1);
-                if (gy < IH) {
-                    const uint32_t v = *(const uint32_t *)(my_stage + row * 192 + col * 4);
-                    *(uint32_t *)(out_img + ((size_t)(2 * (Y0 + 2 * w) + row) * OW + 2 * X0) * 3 + col * 4) = v;
-                }
+            for (int c = 0; c < 2; c++) {
+                const uint32_t v = pack4_relu7(acc[c][0], acc[c][1], acc[c][2], 0);
+                uint8_t *d = my_stage + py * 192 + (2 * (16 * c + m) + px) * 3;
+                d[0] = (uint8_t)v;
+                d[1] = (uint8_t)(v >> 8);
+                d[2] = (uint8_t)(v >> 16);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private staging: no barrier needed
+            __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)out_img, 0, OH * OW * 3, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int idx = k * 64 + lane;                   // dword index in the 2 x 48 tile
+                const int row = idx >= 48 ? 1 : 0, col = idx - 48 * row;
+                const bool ok = idx < 96 && gy < IH;
+                const uint32_t v = *(const uint32_t *)(my_stage + (idx < 96 ? idx : 0) * 4);
+                const uint32_t off = ok ? (uint32_t)(((2 * gy + row) * OW + 2 * X0) * 3 + col * 4) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b32(v, ro, off, 0, 0);
+            }
+            wait_vmcnt<2>();   // the prefetched rows are older than the two stores
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    const int gy = Y0 + 2 * w + i, gx = X0 + 16 * c + m;
-                    if (gy < IH && gx < IW) {
-                        const uint32_t v = pack4_relu7(acc[i][c][0], acc[i][c][1], acc[i][c][2], 0);
-                        uint8_t *dst = out_img + ((size_t)(2 * gy + py) * OW + 2 * gx + px) * 3;
-                        dst[0] = (uint8_t)v;
-                        dst[1] = (uint8_t)(v >> 8);
-                        dst[2] = (uint8_t)(v >> 16);
-                    }
+            for (int c = 0; c < 2; c++) {
+                const int gx = X0 + 16 * c + m;
+                if (gy < IH && gx < IW) {
+                    const uint32_t v = pack4_relu7(acc[c][0], acc[c][1], acc[c][2], 0);
+                    uint8_t *dst = out_img + ((size_t)(2 * gy + py) * OW + 2 * gx + px) * 3;
+                    dst[0] = (uint8_t)v;
+                    dst[1] = (uint8_t)(v >> 8);
+                    dst[2] = (uint8_t)(v >> 16);
                 }
+            }
+            wait_vmcnt<0>();
         }
+        block_barrier();   // next rows landed for every wave, this step's rows are free
+        base += L7_ROWS * L7_PITCH;
+        base = base >= L7_RING_POS ? base - L7_RING_POS : base;
+        pnext += L7_STEP_PIECES;
+        pnext = pnext >= L7_RING_PIECES ? pnext - L7_RING_PIECES : pnext;
     }
 }
 
@@ -376,14 +437,16 @@ hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
 {
     if (g.CIN != 128 || g.COUT != 3) return hipErrorInvalidValue;
     if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB) return hipErrorInvalidValue;
-    const int tiles_x = (g.IW + TILE_X - 1) / TILE_X, tiles_y = (g.IH + TILE_Y - 1) / TILE_Y;
-    int y_chunks = (6144 + tiles_x * n_images - 1) / (tiles_x * n_images);
-    y_chunks = y_chunks < 1 ? 1 : (y_chunks > tiles_y ? tiles_y : y_chunks);
+    if ((size_t)g.OH * g.OW * 3 >= (size_t)OOB) return hipErrorInvalidValue;   // buffer-descriptor stores
+    const int tiles_x = (g.IW + TILE_X - 1) / TILE_X, steps_y = (g.IH + L7_ROWS - 1) / L7_ROWS;
+    int y_chunks = strip_chunks_override();
+    if (y_chunks <= 0) y_chunks = (6144 + tiles_x * n_images - 1) / (tiles_x * n_images);
+    y_chunks = y_chunks < 1 ? 1 : (y_chunks > steps_y ? steps_y : y_chunks);
     const size_t lds = 2 * L7_REGION + 4 * L7_STAGE;
     hipError_t e = hipFuncSetAttribute((const void *)k_l7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_l7, dim3((unsigned)tiles_x, (unsigned)y_chunks, (unsigned)n_images), dim3(256), lds, stream,
-                       in, out, w.d_w_l7, w.d_bias, g.IW, g.IH, g.OW, g.OH, tiles_y, y_chunks, in_layout);
+                       in, out, w.d_w_l7, w.d_bias, g.IW, g.IH, g.OW, g.OH, steps_y, y_chunks, in_layout);
     return hipGetLastError();
 }
 

@@ -91,6 +91,23 @@ def test_layer_matches_oracle_random_weights(api, case):
         assert np.array_equal(got[0], c_oracle.run_layer(d, words, b, x[0], "dataflow_im2col"))
 
 
+@pytest.mark.parametrize("chunks", ["1", "2", "5"])
+@pytest.mark.parametrize("case", [(3, 128, 3, 8, 140, 150, 0), (128, 3, 8, 3, 70, 45, 1), (128, 3, 8, 3, 64, 32, 1)])
+def test_strip_kernels_long_strips(api, case, chunks, monkeypatch):
+    """L0 / L7 walk a vertical strip per workgroup (L7 through a rolling LDS window); force long strips
+    on small images so that ring wrap-around, chunk boundaries and the last partial step are covered."""
+    monkeypatch.setenv("SICN_STRIP_CHUNKS", chunks)
+    rng = np.random.default_rng(abs(hash(case)) % (1 << 32))
+    d = _mk_desc(*case)
+    W, b, words = _rand_params(rng, d)
+    x = rng.integers(0, 256 if d.IFM_CH == 3 else 128, (2,) + d.in_shape, dtype=np.uint8)
+    got = _run_layer(api, d, words, b, x)
+    ref_fn = sicn_ref.deconv522_ref if d.transposed else sicn_ref.conv2d_ref
+    for i in range(2):
+        ref = ref_fn(x[i], W, b)
+        assert np.array_equal(got[i], ref), f"image {i}: {np.count_nonzero(got[i] != ref)} bytes differ"
+
+
 def test_specialised_and_generic_kernels_agree(api):
     from simple_image_compression_network_amd import _lib
     L = _lib.lib()
