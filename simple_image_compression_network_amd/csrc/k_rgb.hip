@@ -254,6 +254,9 @@ hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
 //     c2 = 2*half + (kg>>1) stored at c2 ^ ((P>>2)&3): a 16-lane ds_read_b128 group covers 16
 //     distinct positions at ONE c2, i.e. 16 distinct 16-byte slots of a 256-byte LDS row.  Ring
 //     wrap and step advance are multiples of 16 positions, so the XOR term is a lane constant.
+//     Which channels a K byte stands for is free (W' is packed to match): region R holds the
+//     32-channel groups 2R, 2R+1 whole, so every LDS-DMA lane pair fetches one contiguous 32-byte
+//     group entry (region-interleaved halves made each instruction use half of every line it touched).
 //   * RGB output is transposed through a 384-byte per-wave LDS staging tile and stored as dwords
 //     through a buffer descriptor (masked lanes = out of range), so a step always issues exactly
 //     two stores and the wait for the prefetched rows is a counted vmcnt that leaves them in flight.
@@ -286,7 +289,9 @@ __device__ __forceinline__ void l7_load_rows(uint8_t *patch, const uint8_t *in_i
             const int row = q / L7_PITCH, tx = q - row * L7_PITCH;
             const int iy = iy0 + row, ix = X0 - 1 + tx;
             const bool ok = tx < TILE_X + 2 && iy >= iy_min && iy < IH && ix >= 0 && ix < IW;
-            const uint32_t off = ok ? tensor_offset(tm, iy, ix, (uint32_t)c2) + 16u * region : OOB;
+            // region R keeps channel groups 2R, 2R+1 whole: chunk c2 = 16 bytes (c2&1) of group 2R + (c2>>1), so
+            // a lane pair fetches one contiguous 32-byte group entry and a piece reads whole 512-byte runs
+            const uint32_t off = ok ? tensor_offset(tm, iy, ix, (uint32_t)(2 * region + (c2 >> 1))) + 16u * (c2 & 1) : OOB;
             int slot = pslot0 + kk;
             slot = slot >= L7_RING_PIECES ? slot - L7_RING_PIECES : slot;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(patch + region * L7_REGION + slot * 1024), 16, off, 0, 0, 0);
@@ -425,10 +430,14 @@ void pack_l7(const int8_t *w_okc, int cin, int8_t *dst)
                 const int ph = row >> 2, c = row & 3, py = ph >> 1, px = ph & 1;
                 const int dy = tap / 3, dx = tap % 3, ky = 2 * dy - py, kx = 2 * dx - px;
                 int8_t *t = dst + (((size_t)tap * 2 + half) * 16 + row) * 64;
-                for (int b = 0; b < 64; b++)
+                // K byte b of step `half` is read by lane group kg = b>>4 from LDS region kg&1, chunk
+                // 2*half + (kg>>1): channel 64*(kg&1) + 32*half + 16*(kg>>1) + (b&15)   (see l7_load_rows)
+                for (int b = 0; b < 64; b++) {
+                    const int kg = b >> 4, ch = 64 * (kg & 1) + 32 * half + 16 * (kg >> 1) + (b & 15);
                     t[b] = (c < 3 && ky >= 0 && ky < 5 && kx >= 0 && kx < 5)
-                               ? w_okc[(size_t)c * 25 * cin + (ky * 5 + kx) * cin + half * 64 + b]
+                               ? w_okc[(size_t)c * 25 * cin + (ky * 5 + kx) * cin + ch]
                                : 0;
+                }
             }
 }
 
