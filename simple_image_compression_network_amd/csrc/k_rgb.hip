@@ -261,45 +261,56 @@ hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
 //     through a buffer descriptor (masked lanes = out of range), so a step always issues exactly
 //     two stores and the wait for the prefetched rows is a counted vmcnt that leaves them in flight.
 // =============================================================================================
+#ifndef SICN_L7_AUX
+#define SICN_L7_AUX 0
+#endif
+constexpr int L7_AUX = SICN_L7_AUX;                       // cache policy of the input stream (2 = nt)
 constexpr int L7_PITCH = 36;                             // positions per window row (34 used)
 constexpr int L7_ROWS = 4;                               // input rows per step
 constexpr int L7_STEP_PIECES = L7_ROWS * L7_PITCH / 16;  // 9 LDS-DMA pieces per region per step
-constexpr int L7_RING_PIECES = 23;                       // 368 positions >= 10 rows x 36
+#ifndef SICN_L7_AHEAD
+#define SICN_L7_AHEAD 1
+#endif
+constexpr int L7_AHEAD = SICN_L7_AHEAD;                  // steps of rows in flight ahead of the step being computed
+constexpr int L7_RING_PIECES = ((4 * L7_AHEAD + 6) * L7_PITCH + 15) / 16;   // 1 ahead: 23 pieces = 368 positions >= 10 rows
+constexpr int L7_WGS = L7_AHEAD == 1 ? 3 : 2;            // workgroups per CU the LDS ring allows
 constexpr int L7_RING_POS = L7_RING_PIECES * 16;
 constexpr int L7_REGION = L7_RING_PIECES * 1024;
 constexpr int L7_STAGE = 2 * 192;                        // 2 output rows x 64 pixels x 3 B per wave
-static_assert(L7_ROWS * L7_PITCH % 16 == 0 && L7_RING_POS >= (L7_ROWS + 6) * L7_PITCH, "ring geometry");
+static_assert(L7_ROWS * L7_PITCH % 16 == 0 && L7_RING_POS >= (4 * L7_AHEAD + 6) * L7_PITCH, "ring geometry");
 
 // LDS-DMA pieces `first + 4i` (i < n) of a run of window rows: piece j < npieces covers region
 // j / per_region, positions (j % per_region)*16 .. +15 of the run; row 0 of the run is input row iy0
-// and lands at ring piece slot pslot0.  Rows before `iy_min` (>= 0) are not fetched (zero fill).
+// and lands at ring piece slot pslot0.  Only rows iy_min <= iy < iy_max (inside the image) are
+// fetched, the rest is zero fill.  Every wave issues exactly N loads (the vmcnt bookkeeping of the
+// caller depends on it): a piece index past the run becomes an out-of-range load into `scratch`.
 template <int N>
-__device__ __forceinline__ void l7_load_rows(uint8_t *patch, const uint8_t *in_img, int in_img_bytes, int w, int lane,
-                                             int per_region, int iy0, int iy_min, int pslot0, int X0, int IW, int IH,
-                                             const TensorMap &tm)
+__device__ __forceinline__ void l7_load_rows(uint8_t *patch, uint8_t *scratch, const uint8_t *in_img, int in_img_bytes, int w,
+                                             int lane, int per_region, int iy0, int iy_min, int iy_max, int pslot0, int X0,
+                                             int IW, const TensorMap &tm)
 {
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)in_img, 0, in_img_bytes, 0x00020000);
     const int c2 = (lane & 3) ^ ((lane >> 4) & 3);   // stored chunk (lane&3) of position P holds c2 ^ ((P>>2)&3)
 #pragma unroll
     for (int i = 0; i < N; i++) {
         const int j = w + 4 * i;
-        if (j < 2 * per_region) {   // wave-uniform
-            const int region = j >= per_region ? 1 : 0, kk = j - region * per_region;
-            const int q = kk * 16 + (lane >> 2);
-            const int row = q / L7_PITCH, tx = q - row * L7_PITCH;
-            const int iy = iy0 + row, ix = X0 - 1 + tx;
-            const bool ok = tx < TILE_X + 2 && iy >= iy_min && iy < IH && ix >= 0 && ix < IW;
-            // region R keeps channel groups 2R, 2R+1 whole: chunk c2 = 16 bytes (c2&1) of group 2R + (c2>>1), so
-            // a lane pair fetches one contiguous 32-byte group entry and a piece reads whole 512-byte runs
-            const uint32_t off = ok ? tensor_offset(tm, iy, ix, (uint32_t)(2 * region + (c2 >> 1))) + 16u * (c2 & 1) : OOB;
-            int slot = pslot0 + kk;
-            slot = slot >= L7_RING_PIECES ? slot - L7_RING_PIECES : slot;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(patch + region * L7_REGION + slot * 1024), 16, off, 0, 0, 0);
-        }
+        const bool real = j < 2 * per_region;   // wave-uniform
+        const int region = j >= per_region ? 1 : 0, kk = j - region * per_region;
+        const int q = kk * 16 + (lane >> 2);
+        const int row = q / L7_PITCH, tx = q - row * L7_PITCH;
+        const int iy = iy0 + row, ix = X0 - 1 + tx;
+        const bool ok = real && tx < TILE_X + 2 && iy >= iy_min && iy < iy_max && ix >= 0 && ix < IW;
+        // region R keeps channel groups 2R, 2R+1 whole: chunk c2 = 16 bytes (c2&1) of group 2R + (c2>>1), so
+        // a lane pair fetches one contiguous 32-byte group entry and a piece reads whole 512-byte runs
+        const uint32_t off = ok ? tensor_offset(tm, iy, ix, (uint32_t)(2 * region + (c2 >> 1))) + 16u * (c2 & 1) : OOB;
+        int slot = pslot0 + kk;
+        slot = slot >= L7_RING_PIECES ? slot - L7_RING_PIECES : slot;
+        uint8_t *dst = real ? patch + region * L7_REGION + slot * 1024 : scratch;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst), 16, off, 0, 0, L7_AUX);
     }
 }
 
-__global__ __launch_bounds__(256, 3) void k_l7(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                const int8_t *__restrict__ w_l7,
                                                const int8_t *__restrict__ bias, int IW, int IH, int OW,
                                                int OH, int steps_y, int y_chunks, int in_layout)
@@ -308,6 +319,7 @@ __global__ __launch_bounds__(256, 3) void k_l7(const uint8_t *__restrict__ in, u
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *patch = smem;
     uint8_t *stage = smem + 2 * L7_REGION;
+    uint8_t *scratch = stage + 4 * L7_STAGE;   // 1 KiB sink of the padding loads
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -334,8 +346,20 @@ __global__ __launch_bounds__(256, 3) void k_l7(const uint8_t *__restrict__ in, u
     // window row r <-> input row 4*s_begin - 3 + r; rows 0,1 are never read (they only make the
     // prologue a whole number of pieces)
     const int iy_top = 4 * s_begin - 3;
+    const int iy_max = min(IH, 4 * s_end + 1);   // last row this chunk reads
     const TensorMap tm = tensor_map(in_layout, CIN, IW, IH);
-    l7_load_rows<9>(patch, in_img, in_img_bytes, w, lane, 2 * L7_STEP_PIECES, iy_top, max(iy_top + 2, 0), 0, X0, IW, IH, tm);
+    l7_load_rows<9>(patch, scratch, in_img, in_img_bytes, w, lane, 2 * L7_STEP_PIECES, iy_top, max(iy_top + 2, 0), iy_max, 0, X0,
+                    IW, tm);
+    // block k = window rows 4k+4 .. 4k+7 = the rows step k adds; blocks 1 .. AHEAD-1 start now
+    int pnext = 2 * L7_STEP_PIECES;        // ring piece slot of the next block to be requested
+    int ynext = iy_top + 8;                // its first input row
+#pragma unroll
+    for (int k = 1; k < L7_AHEAD; k++) {
+        l7_load_rows<5>(patch, scratch, in_img, in_img_bytes, w, lane, L7_STEP_PIECES, ynext, 0, iy_max, pnext, X0, IW, tm);
+        ynext += L7_ROWS;
+        pnext += L7_STEP_PIECES;
+        pnext = pnext >= L7_RING_PIECES ? pnext - L7_RING_PIECES : pnext;
+    }
 
     // per-lane fragment addressing: P = (4t + 2 + w + dy)*36 + 16c + m + dx
     uint32_t fa[9], fs[9];
@@ -346,15 +370,15 @@ __global__ __launch_bounds__(256, 3) void k_l7(const uint8_t *__restrict__ in, u
         fa[tap] = a;
         fs[tap] = (uint32_t)((kg & 1) * L7_REGION) + ((((uint32_t)(kg >> 1)) ^ ((a >> 2) & 3u)) << 4);
     }
-    wait_vmcnt<0>();
+    wait_vmcnt<5 * (L7_AHEAD - 1)>();
     block_barrier();
 
-    int base = 0;                          // (144 t) mod 368: ring slot of window row 4t, column 0
-    int pnext = 2 * L7_STEP_PIECES;        // (9t + 18) mod 23: ring piece slot of window row 4t + 8
+    int base = 0;                          // (144 t) mod ring: ring slot of window row 4t, column 0
     for (int s = s_begin; s < s_end; s++) {
         const int Y = 4 * s;               // first input row of this step
-        if (s + 1 < s_end)
-            l7_load_rows<5>(patch, in_img, in_img_bytes, w, lane, L7_STEP_PIECES, Y + 5, 0, pnext, X0, IW, IH, tm);
+        // always issued (rows past the chunk are zero fill): the counted waits below rely on it
+        l7_load_rows<5>(patch, scratch, in_img, in_img_bytes, w, lane, L7_STEP_PIECES, ynext, 0, iy_max, pnext, X0, IW, tm);
+        ynext += L7_ROWS;
 
         v4i acc[2];
         acc[0] = acc[1] = v4i{b0, b1, b2, 0};  // C row 4*kg + r = phase kg, channel r
@@ -396,7 +420,8 @@ __global__ __launch_bounds__(256, 3) void k_l7(const uint8_t *__restrict__ in, u
                 const uint32_t off = ok ? (uint32_t)(((2 * gy + row) * OW + 2 * X0) * 3 + col * 4) : OOB;
                 __builtin_amdgcn_raw_buffer_store_b32(v, ro, off, 0, 0);
             }
-            wait_vmcnt<2>();   // the prefetched rows are older than the two stores
+            // leave in flight: this step's 2 stores and the AHEAD-1 younger row blocks (5 loads + 2 stores each)
+            wait_vmcnt<2 + 7 * (L7_AHEAD - 1)>();
         } else {
 #pragma unroll
             for (int c = 0; c < 2; c++) {
@@ -417,6 +442,7 @@ __global__ __launch_bounds__(256, 3) void k_l7(const uint8_t *__restrict__ in, u
         pnext += L7_STEP_PIECES;
         pnext = pnext >= L7_RING_PIECES ? pnext - L7_RING_PIECES : pnext;
     }
+    wait_vmcnt<0>();   // the zero-fill tail of the prefetch must land before the LDS is released
 }
 
 size_t l7_bytes(int cin) { return (size_t)18 * 16 * 64 * (cin / 128); }
@@ -451,7 +477,7 @@ hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
     int y_chunks = strip_chunks_override();
     if (y_chunks <= 0) y_chunks = (6144 + tiles_x * n_images - 1) / (tiles_x * n_images);
     y_chunks = y_chunks < 1 ? 1 : (y_chunks > steps_y ? steps_y : y_chunks);
-    const size_t lds = 2 * L7_REGION + 4 * L7_STAGE;
+    const size_t lds = 2 * L7_REGION + 4 * L7_STAGE + 1024;
     hipError_t e = hipFuncSetAttribute((const void *)k_l7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_l7, dim3((unsigned)tiles_x, (unsigned)y_chunks, (unsigned)n_images), dim3(256), lds, stream,
