@@ -20,47 +20,36 @@ namespace sicn {
 // slots 5..7 and for the X byte (whatever data sits there is multiplied by 0).
 // Same work split as k_mfma: 8 x 32 output tile, wave w = rows 2w, 2w+1, all output channels.
 // =============================================================================================
-constexpr int L0_ROWS = 2 * TILE_Y + 3;       // 19 input rows per tile
-constexpr int L0_QUADS = 18;                  // 4-pixel groups per row: 72 slots >= 2*31+4+4
+constexpr int L0_QUADS = 18;                  // 4-pixel groups per patch row: 72 slots >= 2*31+4+4
 constexpr int L0_PITCH = L0_QUADS * 16;       // 288 bytes, 16-byte aligned rows
+constexpr int L0_TY = 8;                      // output rows per tile (wave w = rows 2w, 2w+1)
+constexpr int L0_ROWS = 2 * L0_TY + 3;        // 19 input rows per tile
 constexpr int L0_NQUAD = L0_ROWS * L0_QUADS;  // 342 quads per tile, <= 2 per thread
 constexpr int L0_PATCH = L0_ROWS * L0_PITCH;  // 5472 bytes
+#ifndef SICN_L0_CHUNK
+#define SICN_L0_CHUNK 9
+#endif
+constexpr int L0_CHUNK = SICN_L0_CHUNK;       // tiles a workgroup walks at most (its raw pixels are LDS-resident)
+constexpr int L0_RAW_DW = 52;                 // dwords kept per input row: 67 pixels = 201 B + 3 B of alignment slack
+constexpr int L0_RAW_ROWS = 2 * L0_TY * L0_CHUNK + 3;
+constexpr int L0_RAW_BYTES = (L0_RAW_ROWS * L0_RAW_DW * 4 + 12 + 255) / 256 * 256;   // + the 3 dwords the last quad over-reads
 
-// One quad = 4 consecutive input pixels (12 bytes at an arbitrary byte alignment) of one patch row,
-// fetched as 4 aligned dwords through a buffer descriptor (reads past either end of the image
-// return 0) and re-aligned in registers.
-struct L0Quad {
-    uint32_t d[4];
-};
-
-__device__ __forceinline__ void l0_quad_fetch(L0Quad &q, const uint8_t *tensor, int tensor_bytes4, int img_byte0,
-                                              int quad, int Y0, int X0, int IW, int IH)
-{
-    // descriptor over the WHOLE input tensor (its base is allocator-aligned; an image base need
-    // not be 4-byte aligned), size rounded up to a dword so the last partial dword is readable
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)tensor, 0, tensor_bytes4, 0x00020000);
-    const int r = quad / L0_QUADS, g = quad - r * L0_QUADS;
-    const int iy = 2 * Y0 - 2 + r, ix0 = 2 * X0 - 2 + 4 * g;
-    const bool row_ok = quad < L0_NQUAD && iy >= 0 && iy < IH;
-    const int a = (img_byte0 + (iy * IW + ix0) * 3) & ~3;   // negative only left of the very first pixel
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int o = a + 4 * k;
-        q.d[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (row_ok && o >= 0) ? (uint32_t)o : OOB, 0, 0);
-    }
-}
-
-__device__ __forceinline__ void l0_quad_store(const L0Quad &q, uint8_t *patch, int img_byte0, int quad, int Y0, int X0,
-                                              int IW, int IH)
+// raw rows -> RGBX patch: quad = 4 consecutive pixels of one patch row = 12 bytes starting `sh`
+// bytes into dwords 3g .. 3g+3 of the raw row (sh = byte phase of the row's first dword),
+// re-aligned in registers; pixels outside the image become 0 (the raw row holds the neighbouring
+// row's bytes there).  `raw` points at the raw row of patch row 0.
+__device__ __forceinline__ void l0_expand(const uint8_t *raw, uint8_t *patch, int img_byte0, int quad, int Y0, int X0,
+                                          int IW, int IH)
 {
     if (quad >= L0_NQUAD) return;
     const int r = quad / L0_QUADS, g = quad - r * L0_QUADS;
     const int iy = 2 * Y0 - 2 + r, ix0 = 2 * X0 - 2 + 4 * g;
-    const uint32_t sh = (uint32_t)(img_byte0 + (iy * IW + ix0) * 3) & 3u;
-    // 12 payload bytes starting `sh` bytes into d[0..3]
-    const uint32_t w0 = __builtin_amdgcn_alignbyte(q.d[1], q.d[0], sh);
-    const uint32_t w1 = __builtin_amdgcn_alignbyte(q.d[2], q.d[1], sh);
-    const uint32_t w2 = __builtin_amdgcn_alignbyte(q.d[3], q.d[2], sh);
+    const uint32_t sh = (uint32_t)(img_byte0 + (iy * IW + 2 * X0 - 2) * 3) & 3u;
+    const uint32_t *src = (const uint32_t *)(raw + (r * L0_RAW_DW + 3 * g) * 4);
+    const uint32_t d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3];   // g = 17 runs 3 dwords into the next row: zero-weight slots
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    const uint32_t w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    const uint32_t w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
     const bool row_ok = iy >= 0 && iy < IH;
     uint4 v;
     v.x = (row_ok && ix0 + 0 >= 0 && ix0 + 0 < IW) ? (w0 & 0xFFFFFFu) : 0u;
@@ -70,68 +59,92 @@ __device__ __forceinline__ void l0_quad_store(const L0Quad &q, uint8_t *patch, i
     *(uint4 *)(patch + quad * 16) = v;
 }
 
-// Persistent over a vertical strip of tiles.  Per tile: the NEXT tile's pixels are fetched into
-// registers before the MFMAs of the current tile and written to the other LDS patch after them
-// (issue early / write late), and the output stores of a tile are issued last, so the only
-// vmcnt(0) of an iteration waits for loads that had a whole MFMA phase to land and for stores of
-// the previous iteration.
+// One workgroup = a vertical run of up to L0_CHUNK tiles of one 32-pixel strip.  The output stores
+// of this kernel complete slowly when the chip streams 4-6 TB/s of them, and vmcnt retires in
+// order: a wait for ANY load issued after a tile's stores is a wait for those stores (with one wait
+// per tile the kernel ran at 4.5 TB/s of stores even without its MFMAs).  So the loop contains no
+// load at all: the raw pixels of the whole run (3 B/pixel: 30 KB for 9 tiles), the weights and the
+// bias are brought into LDS by one burst of LDS-DMA in the prologue, and per tile the kernel only
+// expands the next tile's pixels LDS -> LDS, runs its MFMAs and issues its 8 stores per wave
+// (lanes outside the image: out-of-range offset of a buffer descriptor), separated by a raw barrier.
+// The two workgroups of a CU cover each other's prologue.
 template <int NTJ>
 __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                const int8_t *__restrict__ w_l0,
                                                const int8_t *__restrict__ bias, int IW, int IH, int OW,
-                                               int OH, int tiles_y, int y_chunks, int out_layout)
+                                               int OH, int tiles_y, int ty_per, int out_layout)
 {
     constexpr int COUT = NTJ * 32;
     constexpr int TB = COUT * KSTEP;
     constexpr int WBYTES = 5 * TB;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *wl = smem;
-    uint8_t *patch0 = smem + WBYTES;  // two patches of L0_PATCH bytes (16-byte multiples)
+    uint8_t *patch0 = smem + WBYTES;                  // two patches of L0_PATCH bytes (16-byte multiples)
+    uint8_t *bias_lds = patch0 + 2 * L0_PATCH;
+    uint8_t *raw = bias_lds + 128;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 31, kh = lane >> 5;
     const int img = blockIdx.z;
     const int X0 = blockIdx.x * TILE_X;
-    const int ty_per = (tiles_y + y_chunks - 1) / y_chunks;
-    const int ty_begin = blockIdx.y * ty_per, ty_end = min(tiles_y, ty_begin + ty_per);
+    const int ty_begin = blockIdx.y * ty_per, ty_end = min(tiles_y, ty_begin + ty_per);   // ty_per <= L0_CHUNK
     if (ty_begin >= ty_end) return;  // before any LDS-DMA is issued
-
-    // weights: 5 tiles of [COUT][32 B] (row permutation + half swizzle as in k_mfma), linear copy
-    for (int piece = w; piece < WBYTES / 1024; piece += 4)
-        __builtin_amdgcn_global_load_lds(GLB_PTR(w_l0 + piece * 1024 + lane * 16), LDS_PTR(wl + piece * 1024),
-                                         16, 0, 0);
-    uint32_t wrow[NTJ];
-#pragma unroll
-    for (int j = 0; j < NTJ; j++) wrow[j] = (uint32_t)((j * 32 + m) * 32 + ((kh ^ ((m >> 3) & 1)) << 4));
 
     const int im_bytes = IH * IW * 3;
     const int img_byte0 = img * im_bytes;                       // launch_l0 guarantees the tensor is < 2 GiB
     const int tensor_bytes4 = ((int)gridDim.z * im_bytes + 3) & ~3;
     uint8_t *out_img = out + (size_t)img * OH * OW * COUT;
+    const TensorMap om = tensor_map(out_layout, COUT, OW, OH);
 
-    L0Quad qa, qb;
-    l0_quad_fetch(qa, in, tensor_bytes4, img_byte0, tid, ty_begin * TILE_Y, X0, IW, IH);
-    l0_quad_fetch(qb, in, tensor_bytes4, img_byte0, tid + 256, ty_begin * TILE_Y, X0, IW, IH);
-    wait_vmcnt<0>();
-    l0_quad_store(qa, patch0, img_byte0, tid, ty_begin * TILE_Y, X0, IW, IH);
-    l0_quad_store(qb, patch0, img_byte0, tid + 256, ty_begin * TILE_Y, X0, IW, IH);
+    // ---- prologue: everything this workgroup will ever read ------------------------------------
+    {
+        // raw rows 2*Y - 2 .. of the run, 52 dwords each from the dword holding pixel 2*X0-2: lane l of
+        // instruction k fetches dword idx = 64k + l (row idx / 52, dword idx % 52) through a descriptor over
+        // the WHOLE input tensor (its base is allocator-aligned, an image base need not be; rows outside the
+        // image and offsets outside the tensor read 0)
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, tensor_bytes4, 0x00020000);
+        const int rows = 2 * L0_TY * (ty_end - ty_begin) + 3;
+        const int n_instr = (rows * L0_RAW_DW + 63) / 64;
+        for (int k = w; k < n_instr; k += 4) {
+            const int idx = 64 * k + lane;
+            const int r = idx / L0_RAW_DW, c = idx - r * L0_RAW_DW;
+            const int iy = 2 * L0_TY * ty_begin - 2 + r;
+            const int o = ((img_byte0 + (iy * IW + 2 * X0 - 2) * 3) & ~3) + 4 * c;   // negative only left of the very first pixel
+            const bool ok = r < rows && iy >= 0 && iy < IH && o >= 0;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(raw + k * 256), 4, ok ? (uint32_t)o : OOB, 0, 0, 0);
+        }
+        // weights: 5 tiles of [COUT][32 B] (row permutation + half swizzle as in k_mfma), linear copy
+        for (int piece = w; piece < WBYTES / 1024; piece += 4)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(w_l0 + piece * 1024 + lane * 16), LDS_PTR(wl + piece * 1024), 16, 0, 0);
+        if (tid < COUT / 4) ((uint32_t *)bias_lds)[tid] = ((const uint32_t *)bias)[tid];
+    }
+    uint32_t wrow[NTJ];
+#pragma unroll
+    for (int j = 0; j < NTJ; j++) wrow[j] = (uint32_t)((j * 32 + m) * 32 + ((kh ^ ((m >> 3) & 1)) << 4));
+    // the builtin (not inline asm): hipcc then KNOWS no LDS-DMA is pending and puts no vmcnt(0) of
+    // its own in front of the LDS accesses of the loop
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    block_barrier();
+    l0_expand(raw, patch0, img_byte0, tid, ty_begin * L0_TY, X0, IW, IH);
+    l0_expand(raw, patch0, img_byte0, tid + 256, ty_begin * L0_TY, X0, IW, IH);
     block_barrier();
 
     int buf = 0;
     for (int tile_y = ty_begin; tile_y < ty_end; tile_y++, buf ^= 1) {
-        const int Y0 = tile_y * TILE_Y;
+        const int Y0 = tile_y * L0_TY;
         const uint8_t *patch = patch0 + buf * L0_PATCH;
-        const bool more = tile_y + 1 < ty_end;
-        if (more) {  // issue early
-            l0_quad_fetch(qa, in, tensor_bytes4, img_byte0, tid, Y0 + TILE_Y, X0, IW, IH);
-            l0_quad_fetch(qb, in, tensor_bytes4, img_byte0, tid + 256, Y0 + TILE_Y, X0, IW, IH);
+        if (tile_y + 1 < ty_end) {   // pixels of the next tile -> the patch nobody reads in this iteration
+            const uint8_t *rsrc = raw + (tile_y + 1 - ty_begin) * (2 * L0_TY * L0_RAW_DW * 4);
+            uint8_t *nxt = patch0 + (buf ^ 1) * L0_PATCH;
+            l0_expand(rsrc, nxt, img_byte0, tid, Y0 + L0_TY, X0, IW, IH);
+            l0_expand(rsrc, nxt, img_byte0, tid + 256, Y0 + L0_TY, X0, IW, IH);
         }
 
         v16i acc[2][NTJ];
 #pragma unroll
         for (int j = 0; j < NTJ; j++) {
-            const v4i b4 = *(const v4i *)(bias + j * 32 + 16 * kh);
+            const v4i b4 = *(const v4i *)(bias_lds + j * 32 + 16 * kh);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int bv = (int)(int8_t)((uint32_t)b4[r >> 2] >> (8 * (r & 3)));
@@ -158,32 +171,24 @@ __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, u
                     acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[j], pf[i], acc[i][j], 0, 0, 0);
         }
 #endif
-        if (more) {  // write late: into the patch nobody reads during this iteration
-            wait_vmcnt<0>();
-            uint8_t *nxt = patch0 + (buf ^ 1) * L0_PATCH;
-            l0_quad_store(qa, nxt, img_byte0, tid, Y0 + TILE_Y, X0, IW, IH);
-            l0_quad_store(qb, nxt, img_byte0, tid + 256, Y0 + TILE_Y, X0, IW, IH);
-        }
+        __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)out_img, 0, OH * OW * COUT, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int gy = Y0 + 2 * w + i, gx = X0 + m;
-            if (gy < OH && gx < OW) {
+            const bool ok = gy < OH && gx < OW;
 #pragma unroll
-                for (int j = 0; j < NTJ; j++) {
-                    const v16i a = acc[i][j];
-                    uint4 v;
-                    v.x = pack4_relu7(a[0], a[1], a[2], a[3]);
-                    v.y = pack4_relu7(a[4], a[5], a[6], a[7]);
-                    v.z = pack4_relu7(a[8], a[9], a[10], a[11]);
-                    v.w = pack4_relu7(a[12], a[13], a[14], a[15]);
-#ifdef SICN_EXP_L0_NO_STORE
-                    if (v.x != 0xffffffffu) continue;   // never true after relu7, the compiler cannot know
-#endif
-                    *(uint4 *)(out_img + tensor_offset(out_layout, gy, gx, (uint32_t)j, COUT, OW, OH) + 16 * kh) = v;
-                }
+            for (int j = 0; j < NTJ; j++) {
+                const v16i a = acc[i][j];
+                v4i v;
+                v[0] = (int)pack4_relu7(a[0], a[1], a[2], a[3]);
+                v[1] = (int)pack4_relu7(a[4], a[5], a[6], a[7]);
+                v[2] = (int)pack4_relu7(a[8], a[9], a[10], a[11]);
+                v[3] = (int)pack4_relu7(a[12], a[13], a[14], a[15]);
+                const uint32_t off = ok ? tensor_offset(om, gy, gx, (uint32_t)j) + 16u * kh : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(v, ro, off, 0, 0);
             }
         }
-        block_barrier();  // next patch complete, this patch free (raw barrier: stores stay in flight)
+        block_barrier();  // next patch complete, this patch free (raw barrier: the stores stay in flight)
     }
 }
 
@@ -219,17 +224,22 @@ void pack_l0(const int8_t *w_okc, int cout, int8_t *dst)
 hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
                      int n_images, hipStream_t stream, int out_layout)
 {
-    const int tiles_x = (g.OW + TILE_X - 1) / TILE_X, tiles_y = (g.OH + TILE_Y - 1) / TILE_Y;
-    int y_chunks = strip_chunks_override();
-    if (y_chunks <= 0) y_chunks = (4096 + tiles_x * n_images - 1) / (tiles_x * n_images);
-    y_chunks = y_chunks < 1 ? 1 : (y_chunks > tiles_y ? tiles_y : y_chunks);
+    const int tiles_x = (g.OW + TILE_X - 1) / TILE_X, tiles_y = (g.OH + L0_TY - 1) / L0_TY;
+    // runs of at most L0_CHUNK tiles (the LDS holds a run's pixels), evened out; the test hook can only shorten them
+    int y_chunks = (tiles_y + L0_CHUNK - 1) / L0_CHUNK;
+    const int forced = strip_chunks_override();
+    if (forced > y_chunks) y_chunks = forced > tiles_y ? tiles_y : forced;
+    const int ty_per = (tiles_y + y_chunks - 1) / y_chunks;
+    y_chunks = (tiles_y + ty_per - 1) / ty_per;
     dim3 grid((unsigned)tiles_x, (unsigned)y_chunks, (unsigned)n_images);
     if ((size_t)g.IH * g.IW * 3 * (size_t)n_images + 4 >= (size_t)OOB) return hipErrorInvalidValue;
-    if ((size_t)g.OH * g.OW * g.COUT >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // 32-bit store offsets
+    if ((size_t)g.OH * g.OW * g.COUT >= (size_t)OOB) return hipErrorInvalidValue;   // buffer-descriptor stores
     if (g.COUT == 128) {
-        const size_t lds = 5 * 128 * KSTEP + 2 * L0_PATCH;
+        const size_t lds = 5 * 128 * KSTEP + 2 * L0_PATCH + 128 + L0_RAW_BYTES;
+        hipError_t e = hipFuncSetAttribute((const void *)k_l0<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_l0<4>, grid, dim3(256), lds, stream, in, out, w.d_w_l0, w.d_bias, g.IW, g.IH,
-                           g.OW, g.OH, tiles_y, y_chunks, out_layout);
+                           g.OW, g.OH, tiles_y, ty_per, out_layout);
     } else
         return hipErrorInvalidValue;
     return hipGetLastError();
