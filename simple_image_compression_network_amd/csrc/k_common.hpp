@@ -119,6 +119,20 @@ __device__ __forceinline__ void load_piece(uint8_t *patch, const uint8_t *in_img
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(patch + sub * SUB_ALLOC + k * 1024), 16, off, 0, 0, 0);
 }
 
+// XCD-aware work mapping.  Workgroups of a 1-D grid are dealt to the 8 XCDs round-robin (linear id % 8)
+// and each XCD has its own L2, so neighbouring tiles / strips (which share halo pixels and the 128-byte
+// lines at their common edge) should run on the SAME XCD at about the same time: XCD x works through
+// the contiguous range [x * per, (x+1) * per) of the logical work list.  Returns the logical index of
+// this workgroup, or -1 if it has none (the grid is padded to a multiple of 8).
+constexpr int N_XCD = 8;
+__device__ __forceinline__ int xcd_logical_index(int n_items)
+{
+    const int per = (n_items + N_XCD - 1) / N_XCD;
+    const int l = (int)blockIdx.x, idx = (l % N_XCD) * per + l / N_XCD;
+    return (l / N_XCD < per && idx < n_items) ? idx : -1;
+}
+__host__ inline unsigned xcd_grid_size(int n_items) { return (unsigned)((n_items + N_XCD - 1) / N_XCD * N_XCD); }
+
 // ---- conv tap order: by parity plane (a,b) = (ky&1, kx&1), so that a plane's LDS buffer is
 // ---- free for the next channel group as soon as its taps are done (k_mfma.hip) -------------
 struct Tap { int ky, kx; };

@@ -31,8 +31,16 @@ namespace sicn {
 #ifndef SICN_RING16
 #define SICN_RING16 8
 #endif
-constexpr int PF16 = SICN_PF16;      // weight tiles (K steps) in flight ahead of the consumer, even
+#ifndef SICN_WAIT_PASSES
+#define SICN_WAIT_PASSES 2
+#endif
+constexpr int PF16 = SICN_PF16;      // weight tiles (K steps) requested ahead of the consumer, even
 constexpr int RING16 = SICN_RING16;  // >= PF16 + 2
+// A pass needs the tiles of the NEXT pass at its barrier; they were requested PF16/2 = 3 passes
+// earlier, so the requests of the last WAITP = 2 passes may still be in flight there (1 = the
+// stricter wait of the first version: only the pass's own requests).
+constexpr int WAITP = SICN_WAIT_PASSES;
+static_assert(WAITP >= 1 && WAITP <= PF16 / 2 - 1, "tiles of pass k+1 were requested in pass k+1-PF16/2");
 
 template <int TB>
 __device__ __forceinline__ void load_wtile16(uint8_t *ring, const int8_t *wstream, int tile, int lane, int w)
@@ -95,28 +103,30 @@ __device__ __forceinline__ void pass16(v4i (&acc)[4][NT16], const uint8_t *patch
     block_barrier();
 }
 
+// Always issues 4 * NT16/4 stores per wave (positions outside the image go to an out-of-range offset
+// of a buffer descriptor, which drops them): the counted waits of the following passes rely on it.
 template <int NT16>
 __device__ __forceinline__ void store_tiles16(const v4i (&acc)[4][NT16], uint8_t *out_img, int OW, int OH, int MW, int MH,
                                               int Y0, int X0, int w, int pos, int g, bool deconv, int py, int px,
                                               int out_layout)
 {
     constexpr int COUT = NT16 * 16;
+    __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)out_img, 0, OH * OW * COUT, 0x00020000);
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const int gy = Y0 + 2 * w + (c >> 1), gx = X0 + (c & 1) * 16 + pos;
-        if (gy < MH && gx < MW) {
-            const int oy_ = deconv ? 2 * gy + py : gy, ox_ = deconv ? 2 * gx + px : gx;
+        const bool ok = gy < MH && gx < MW;
+        const int oy_ = deconv ? 2 * gy + py : gy, ox_ = deconv ? 2 * gx + px : gx;
 #pragma unroll
-            for (int J = 0; J < NT16 / 4; J++) {
-                uint4 v;
-                v.x = pack4_relu7(acc[c][4 * J + 0][0], acc[c][4 * J + 0][1], acc[c][4 * J + 0][2], acc[c][4 * J + 0][3]);
-                v.y = pack4_relu7(acc[c][4 * J + 1][0], acc[c][4 * J + 1][1], acc[c][4 * J + 1][2], acc[c][4 * J + 1][3]);
-                v.z = pack4_relu7(acc[c][4 * J + 2][0], acc[c][4 * J + 2][1], acc[c][4 * J + 2][2], acc[c][4 * J + 2][3]);
-                v.w = pack4_relu7(acc[c][4 * J + 3][0], acc[c][4 * J + 3][1], acc[c][4 * J + 3][2], acc[c][4 * J + 3][3]);
-                // channels 64J + 16g .. +15 = channel group 2J + (g>>1), second half iff g odd
-                const uint32_t off = tensor_offset(out_layout, oy_, ox_, (uint32_t)(2 * J + (g >> 1)), COUT, OW, OH) + 16 * (g & 1);
-                *(uint4 *)(out_img + off) = v;
-            }
+        for (int J = 0; J < NT16 / 4; J++) {
+            v4i v;
+            v[0] = (int)pack4_relu7(acc[c][4 * J + 0][0], acc[c][4 * J + 0][1], acc[c][4 * J + 0][2], acc[c][4 * J + 0][3]);
+            v[1] = (int)pack4_relu7(acc[c][4 * J + 1][0], acc[c][4 * J + 1][1], acc[c][4 * J + 1][2], acc[c][4 * J + 1][3]);
+            v[2] = (int)pack4_relu7(acc[c][4 * J + 2][0], acc[c][4 * J + 2][1], acc[c][4 * J + 2][2], acc[c][4 * J + 2][3]);
+            v[3] = (int)pack4_relu7(acc[c][4 * J + 3][0], acc[c][4 * J + 3][1], acc[c][4 * J + 3][2], acc[c][4 * J + 3][3]);
+            // channels 64J + 16g .. +15 = channel group 2J + (g>>1), second half iff g odd
+            const uint32_t off = ok ? tensor_offset(out_layout, oy_, ox_, (uint32_t)(2 * J + (g >> 1)), COUT, OW, OH) + 16 * (g & 1) : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(v, ro, off, 0, 0);
         }
     }
 }
@@ -174,7 +184,12 @@ __device__ __forceinline__ void conv_passes16(v4i (&acc)[4][NT16], const Conv16C
     // (3) MFMAs; the wait leaves exactly this pass's own loads in flight
     const uint32_t pix = c.lane_pix + (c.hi ? offB : offA);
     const uint32_t wt = c.lane_wt + (uint32_t)(((c.hi ? stepB : stepA) % RING16) * TB);
-    pass16<NT16, 2 * WR + (rpA >= 0) + (rpB >= 0), 0>(acc, c.patch, c.ring, pix, wt, false);
+    // requests of this pass, plus (WAITP == 2) those of the previous one: steps SA-2, SA-1 (the previous
+    // window's last pass for P == 0; before the first window nothing is outstanding, which only helps)
+    constexpr int TPa = (SA + 48) % 25, TPb = (SA + 49) % 25;
+    constexpr int own = 2 * WR + (rpA >= 0) + (rpB >= 0);
+    constexpr int prev = 2 * WR + (refresh16_plane(TPa) >= 0) + (refresh16_plane(TPb) >= 0);
+    pass16<NT16, own + (WAITP - 1) * prev, 0>(acc, c.patch, c.ring, pix, wt, false);
     if constexpr (P + 1 < 25) conv_passes16<NT16, P + 1>(acc, c, poff, q0, qstride);
 }
 
@@ -238,9 +253,9 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
                     load_wtile16<TB>(ring, wstream, step + q + 1 + PF16, lane, w);
                     const uint32_t pix = lane_pix + tap_off + (uint32_t)((q + hi) * SUB_ALLOC);
                     const uint32_t wt = lane_wt + (uint32_t)(((step + q + hi) % RING16) * TB);
-                    // first pass of a phase: the previous phase's 2*NT16/4 stores are younger than the
+                    // first WAITP passes of a phase: the previous phase's NT16 stores are younger than the
                     // awaited tiles — count them instead of waiting for them
-                    pass16<NT16, 2 * WR, NT16>(acc, patch, ring, pix, wt, ph > 0 && t == 0 && q == 0);
+                    pass16<NT16, 2 * WR * WAITP, NT16>(acc, patch, ring, pix, wt, ph > 0 && t == 0 && q < 2 * WAITP);
                 }
                 step += NQ;
             }
@@ -308,7 +323,7 @@ hipError_t launch_mfma16(const LayerGeom &g, const sicn_weights &w, const uint8_
                          hipStream_t stream, int in_layout, int out_layout)
 {
     if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB) return hipErrorInvalidValue;          // 31-bit patch offsets
-    if ((size_t)g.OH * g.OW * g.COUT >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // 32-bit store offsets
+    if ((size_t)g.OH * g.OW * g.COUT >= (size_t)OOB) return hipErrorInvalidValue;         // buffer-descriptor stores
     if (g.transposed) {
         if (g.CIN == 128 && g.COUT == 128) return launch16<4, 8, true>(g, w, in, out, n_images, stream, in_layout, out_layout);
         if (g.CIN == 192 && g.COUT == 128) return launch16<6, 8, true>(g, w, in, out, n_images, stream, in_layout, out_layout);

@@ -323,7 +323,7 @@ __device__ __forceinline__ void l7_load_rows(uint8_t *patch, uint8_t *scratch, c
 __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                const int8_t *__restrict__ w_l7,
                                                const int8_t *__restrict__ bias, int IW, int IH, int OW,
-                                               int OH, int steps_y, int y_chunks, int in_layout)
+                                               int OH, int steps_y, int y_chunks, int tiles_x, int n_images, int in_layout)
 {
     constexpr int CIN = 128;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -333,10 +333,13 @@ __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int img = blockIdx.z;
-    const int X0 = blockIdx.x * TILE_X;
+    // logical work list: strip (fastest), chunk, image — an XCD gets whole rows of neighbouring strips
+    const int item = xcd_logical_index(tiles_x * y_chunks * n_images);
+    if (item < 0) return;
+    const int bx = item % tiles_x, by = (item / tiles_x) % y_chunks, img = item / (tiles_x * y_chunks);
+    const int X0 = bx * TILE_X;
     const int per = (steps_y + y_chunks - 1) / y_chunks;
-    const int s_begin = blockIdx.y * per, s_end = min(steps_y, s_begin + per);
+    const int s_begin = by * per, s_end = min(steps_y, s_begin + per);
     if (s_begin >= s_end) return;  // before any LDS-DMA is issued
 
     // lane roles in v_mfma_i32_16x16x64_i8: A row / B column = lane & 15, K bytes 16*(lane>>4)..+15
@@ -490,8 +493,8 @@ hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
     const size_t lds = 2 * L7_REGION + 4 * L7_STAGE + 1024;
     hipError_t e = hipFuncSetAttribute((const void *)k_l7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_l7, dim3((unsigned)tiles_x, (unsigned)y_chunks, (unsigned)n_images), dim3(256), lds, stream,
-                       in, out, w.d_w_l7, w.d_bias, g.IW, g.IH, g.OW, g.OH, steps_y, y_chunks, in_layout);
+    hipLaunchKernelGGL(k_l7, dim3(xcd_grid_size(tiles_x * y_chunks * n_images)), dim3(256), lds, stream, in, out, w.d_w_l7,
+                       w.d_bias, g.IW, g.IH, g.OW, g.OH, steps_y, y_chunks, tiles_x, n_images, in_layout);
     return hipGetLastError();
 }
 
