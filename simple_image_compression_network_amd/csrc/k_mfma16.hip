@@ -196,8 +196,8 @@ __device__ __forceinline__ void conv_passes16(v4i (&acc)[4][NT16], const Conv16C
 template <int NQ, int NT16, bool DECONV, int MINW>
 __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
     const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int8_t *__restrict__ wstream,
-    const int8_t *__restrict__ bias, int IW, int IH, int OW, int OH, int MW, int MH, int tiles_x, int in_layout,
-    int out_layout)
+    const int8_t *__restrict__ bias, int IW, int IH, int OW, int OH, int MW, int MH, int tiles_x, int n_tiles, int n_images,
+    int in_layout, int out_layout)
 {
     static_assert(NQ % 2 == 0, "channel groups are consumed in pairs");
     constexpr int CIN = NQ * 32, COUT = NT16 * 16;
@@ -211,8 +211,12 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pos = lane & 15, g = lane >> 4, hi = g >> 1, half = g & 1;
-    const int img = blockIdx.z;
-    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+    // logical work list: tile x (fastest), tile y, image; an XCD gets a contiguous range of it, so the
+    // tiles that share halo pixels share an L2 (k_common.hpp)
+    const int item = xcd_logical_index(n_tiles * n_images);
+    if (item < 0) return;   // before any LDS-DMA is issued
+    const int img = item / n_tiles, tile = item - img * n_tiles;
+    const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
     const int Y0 = tile_y * TILE_Y, X0 = tile_x * TILE_X;
 
     const int in_img_bytes = IH * IW * CIN;
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
 #define SICN_INST16(NQ, NT16, D)                                                                                 \
     template __global__ void k_mfma16_t<NQ, NT16, D, ((NT16 <= 8 && NQ <= 4) ? 2 : 1)>(                           \
         const uint8_t *__restrict__, uint8_t *__restrict__, const int8_t *__restrict__, const int8_t *__restrict__, \
-        int, int, int, int, int, int, int, int, int);
+        int, int, int, int, int, int, int, int, int, int, int);
 SICN_INST16(4, 8, true)
 SICN_INST16(6, 8, true)
 SICN_INST16(4, 8, false)
@@ -313,9 +317,9 @@ static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mfma16_t<NQ, NT16, DECONV, MINW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    dim3 grid((unsigned)(tiles_x * tiles_y), 1, (unsigned)n_images);
+    dim3 grid(xcd_grid_size(tiles_x * tiles_y * n_images));
     hipLaunchKernelGGL((k_mfma16_t<NQ, NT16, DECONV, MINW>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias,
-                       g.IW, g.IH, g.OW, g.OH, MW, MH, tiles_x, in_layout, out_layout);
+                       g.IW, g.IH, g.OW, g.OH, MW, MH, tiles_x, tiles_x * tiles_y, n_images, in_layout, out_layout);
     return hipGetLastError();
 }
 

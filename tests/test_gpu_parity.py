@@ -335,9 +335,18 @@ def test_forward_is_graph_capturable(api):
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
-    with torch.cuda.stream(s):
-        with torch.cuda.graph(graph, stream=s):
-            net.forward(x, out, lat)
+    # nets of earlier tests must not be finalised (hipFree / hipEventDestroy are illegal while a
+    # capture is open and would invalidate it) by a garbage collection that happens to run inside
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    gc.disable()
+    try:
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(graph, stream=s):
+                net.forward(x, out, lat)
+    finally:
+        gc.enable()
     x2 = torch.from_numpy(rng.integers(0, 256, (2, 256, 256, 3), dtype=np.uint8)).cuda()
     x.copy_(x2)
     graph.replay()
