@@ -111,6 +111,24 @@ __device__ __forceinline__ uint32_t piece_src_offset(int k, int lane, int Yb, in
     return ok ? tensor_offset(layout, iy, ix, g, C, IW, IH) + hlog * 16 : OOB;
 }
 
+// The same with the layout as strides: patch position and validity of this lane in piece `k`
+// (unswizzled image, 16x16x64 kernels), channel group 0; group g is `+ g * tm.grp`.
+struct PieceSrc {
+    uint32_t off;   // byte offset of channel group 0 (meaningless if !ok)
+    bool ok;
+};
+__device__ __forceinline__ PieceSrc piece_src(const TensorMap &tm, int k, int lane, int Yb, int Xb, int s, int ay, int ax,
+                                              int IW, int IH)
+{
+    const int p = k * 32 + (lane >> 1);
+    const int ty = p / PATCH_X, tx = p - ty * PATCH_X;
+    const int iy = s * (Yb + ty) + ay, ix = s * (Xb + tx) + ax;
+    PieceSrc r;
+    r.ok = p < PATCH_PIX && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
+    r.off = tensor_offset(tm, iy, ix, 0u) + (uint32_t)(lane & 1) * 16u;
+    return r;
+}
+
 // one LDS-DMA piece (1 KiB) of sub-patch `sub`
 __device__ __forceinline__ void load_piece(uint8_t *patch, const uint8_t *in_img, int in_img_bytes, int sub,
                                            int k, uint32_t off)

@@ -79,9 +79,11 @@ __device__ __forceinline__ void init_acc16(v4i (&acc)[4][NT16], const int8_t *bi
 //   pix_off : byte offset of this lane's fragment 0 inside the patch, already including the step
 //             (sub-patch, tap offset) selected by the lane's K half
 //   wt_off  : byte offset of this lane's fragment 0 inside the ring, including the step's slot
-template <int NT16, int VMCNT, int EXTRA>
+//   FIRST   : the accumulators start here: C operand = the bias (unpacked per weight tile into 4
+//             scratch registers) instead of 4 * NT16 * 4 register initialisations before the pass
+template <int NT16, int VMCNT, int EXTRA, bool FIRST = false>
 __device__ __forceinline__ void pass16(v4i (&acc)[4][NT16], const uint8_t *patch, const uint8_t *ring, uint32_t pix_off,
-                                       uint32_t wt_off, bool extra)
+                                       uint32_t wt_off, bool extra, const v4i (&bias4)[NT16 / 4] = {})
 {
     v4i pf[4], wf[NT16];
 #pragma unroll
@@ -89,34 +91,45 @@ __device__ __forceinline__ void pass16(v4i (&acc)[4][NT16], const uint8_t *patch
 #pragma unroll
     for (int j = 0; j < NT16; j++) wf[j] = *(const v4i *)(ring + wt_off + j * 16 * 32);
 #pragma unroll
-    for (int j = 0; j < NT16; j++)
+    for (int j = 0; j < NT16; j++) {
+        v4i cin;
+        if constexpr (FIRST) {   // register r of tile j is channel 64*(j>>2) + 16g + 4*(j&3) + r: byte r of dword j&3 of bias4[j>>2]
 #pragma unroll
-        for (int c = 0; c < 4; c++) acc[c][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[j], pf[c], acc[c][j], 0, 0, 0);
+            for (int r = 0; r < 4; r++) cin[r] = (int)(int8_t)((uint32_t)bias4[j >> 2][j & 3] >> (8 * r));
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            acc[c][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[j], pf[c], FIRST ? cin : acc[c][j], 0, 0, 0);
+    }
 #ifndef SICN_NO_SCHED16
     __builtin_amdgcn_sched_group_barrier(0x100, 4 + NT16, 0);   // all fragment reads first
-    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT16, 0);   // then the MFMA cluster
+    if constexpr (!FIRST) __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT16, 0);   // then the MFMA cluster
 #endif
+#ifdef SICN_EXP_NOWAIT   // timing experiment only (results are wrong): never block on vmcnt inside the loop
+    wait_vmcnt<63>();
+#else
     if (EXTRA > 0 && extra)
         wait_vmcnt<VMCNT + EXTRA>();
     else
         wait_vmcnt<VMCNT>();
+#endif
     block_barrier();
 }
 
 // Always issues 4 * NT16/4 stores per wave (positions outside the image go to an out-of-range offset
 // of a buffer descriptor, which drops them): the counted waits of the following passes rely on it.
 template <int NT16>
-__device__ __forceinline__ void store_tiles16(const v4i (&acc)[4][NT16], uint8_t *out_img, int OW, int OH, int MW, int MH,
-                                              int Y0, int X0, int w, int pos, int g, bool deconv, int py, int px,
-                                              int out_layout)
+__device__ __forceinline__ void store_tiles16(const v4i (&acc)[4][NT16], uint8_t *out_img, int out_img_bytes, const TensorMap &om,
+                                              int MW, int MH, int Y0, int X0, int w, int pos, int g, bool deconv, int py, int px)
 {
-    constexpr int COUT = NT16 * 16;
-    __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)out_img, 0, OH * OW * COUT, 0x00020000);
+    __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)out_img, 0, out_img_bytes, 0x00020000);
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const int gy = Y0 + 2 * w + (c >> 1), gx = X0 + (c & 1) * 16 + pos;
         const bool ok = gy < MH && gx < MW;
         const int oy_ = deconv ? 2 * gy + py : gy, ox_ = deconv ? 2 * gx + px : gx;
+        // channels 64J + 16g .. +15 = channel group 2J + (g>>1), second half iff g odd
+        const uint32_t off0 = tensor_offset(om, oy_, ox_, (uint32_t)(g >> 1)) + 16u * (g & 1);
 #pragma unroll
         for (int J = 0; J < NT16 / 4; J++) {
             v4i v;
@@ -124,9 +137,7 @@ __device__ __forceinline__ void store_tiles16(const v4i (&acc)[4][NT16], uint8_t
             v[1] = (int)pack4_relu7(acc[c][4 * J + 1][0], acc[c][4 * J + 1][1], acc[c][4 * J + 1][2], acc[c][4 * J + 1][3]);
             v[2] = (int)pack4_relu7(acc[c][4 * J + 2][0], acc[c][4 * J + 2][1], acc[c][4 * J + 2][2], acc[c][4 * J + 2][3]);
             v[3] = (int)pack4_relu7(acc[c][4 * J + 3][0], acc[c][4 * J + 3][1], acc[c][4 * J + 3][2], acc[c][4 * J + 3][3]);
-            // channels 64J + 16g .. +15 = channel group 2J + (g>>1), second half iff g odd
-            const uint32_t off = ok ? tensor_offset(out_layout, oy_, ox_, (uint32_t)(2 * J + (g >> 1)), COUT, OW, OH) + 16 * (g & 1) : OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(v, ro, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v, ro, ok ? off0 + (uint32_t)(2 * J) * om.grp : OOB, 0, 0);
         }
     }
 }
@@ -225,19 +236,26 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
     const uint32_t lane_pix = (uint32_t)(((2 * w) * PATCH_X + pos) * 32 + half * 16);
     const uint32_t lane_wt = (uint32_t)(pos * 32 + half * 16);
 
+    const TensorMap im = tensor_map(in_layout, CIN, IW, IH), om = tensor_map(out_layout, COUT, OW, OH);
+    const int out_img_bytes = OH * OW * COUT;
+
     v4i acc[4][NT16];
 
     if constexpr (DECONV) {
         // ---- prologue: the whole patch (NQ channel groups) + PF16 weight tiles -------------------
 #pragma unroll
-        for (int sub = 0; sub < NQ; sub++)
+        for (int slot = 0; slot < 3; slot++) {
+            const PieceSrc ps = piece_src(im, slot * 4 + w, lane, Y0 - 1, X0 - 1, 1, 0, 0, IW, IH);
 #pragma unroll
-            for (int slot = 0; slot < 3; slot++)
-                load_piece(patch, in_img, in_img_bytes, sub, slot * 4 + w,
-                           piece_src_offset(slot * 4 + w, lane, Y0 - 1, X0 - 1, 1, 0, 0, IW, IH, in_layout, (uint32_t)sub, CIN,
-                                            false));
+            for (int sub = 0; sub < NQ; sub++)
+                load_piece(patch, in_img, in_img_bytes, sub, slot * 4 + w, ps.ok ? ps.off + (uint32_t)sub * im.grp : OOB);
+        }
 #pragma unroll
         for (int s = 0; s < PF16; s++) load_wtile16<TB>(ring, wstream, s, lane, w);
+        // this lane's 16 bias bytes per group of 4 weight tiles (channels 64J + 16g .. +15)
+        v4i bias4[NT16 / 4];
+#pragma unroll
+        for (int J = 0; J < NT16 / 4; J++) bias4[J] = *(const v4i *)(bias + 64 * J + 16 * g);
         wait_vmcnt<0>();
         block_barrier();
 
@@ -246,25 +264,34 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
         for (int ph = 0; ph < 4; ph++) {
             const int py = ph >> 1, px = ph & 1;
             const int nkx = 3 - px, ntap = (3 - py) * nkx;
-            init_acc16<NT16>(acc, bias, g);
 #pragma unroll 1
             for (int t = 0; t < ntap; t++) {
                 const int iy = t / nkx, ix = t - iy * nkx;
                 const uint32_t tap_off = (uint32_t)(((iy + py) * PATCH_X + ix + px) * 32);
+                int q0 = 0;
+                if (t == 0) {
+                    // first pass of the phase: the accumulators start at the bias (C operand).  The previous
+                    // phase's NT16 stores are younger than the awaited tiles in the first WAITP passes of a
+                    // phase — count them instead of waiting for them
+                    load_wtile16<TB>(ring, wstream, step + PF16, lane, w);
+                    load_wtile16<TB>(ring, wstream, step + 1 + PF16, lane, w);
+                    const uint32_t pix = lane_pix + tap_off + (uint32_t)(hi * SUB_ALLOC);
+                    const uint32_t wt = lane_wt + (uint32_t)(((step + hi) % RING16) * TB);
+                    pass16<NT16, 2 * WR * WAITP, NT16, true>(acc, patch, ring, pix, wt, ph > 0, bias4);
+                    q0 = 2;
+                }
 #pragma unroll NQ <= 4 ? 2 : 1
-                for (int q = 0; q < NQ; q += 2) {
+                for (int q = q0; q < NQ; q += 2) {
                     load_wtile16<TB>(ring, wstream, step + q + PF16, lane, w);
                     load_wtile16<TB>(ring, wstream, step + q + 1 + PF16, lane, w);
                     const uint32_t pix = lane_pix + tap_off + (uint32_t)((q + hi) * SUB_ALLOC);
                     const uint32_t wt = lane_wt + (uint32_t)(((step + q + hi) % RING16) * TB);
-                    // first WAITP passes of a phase: the previous phase's NT16 stores are younger than the
-                    // awaited tiles — count them instead of waiting for them
                     pass16<NT16, 2 * WR * WAITP, NT16>(acc, patch, ring, pix, wt, ph > 0 && t == 0 && q < 2 * WAITP);
                 }
                 step += NQ;
             }
             if (ph == 3) wait_vmcnt<0>();  // the padded tail of the weight prefetch must land before exit
-            store_tiles16<NT16>(acc, out_img, OW, OH, MW, MH, Y0, X0, w, pos, g, true, py, px, out_layout);
+            store_tiles16<NT16>(acc, out_img, out_img_bytes, om, MW, MH, Y0, X0, w, pos, g, true, py, px);
         }
     } else {
         // ---- per-lane source offsets of the 4 planes x 3 refresh slots (channel group 0) --------
@@ -272,10 +299,11 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
 #pragma unroll
         for (int pl = 0; pl < 4; pl++)
 #pragma unroll
-            for (int slot = 0; slot < 3; slot++)
-                poff[pl][slot] = piece_src_offset(slot * 4 + w, lane, Y0 - 1, X0 - 1, 2, pl >> 1, pl & 1, IW, IH, in_layout, 0u,
-                                                  CIN, false);
-        const uint32_t qstride = in_layout == LAYOUT_GROUP ? (uint32_t)(IW * IH * 32) : 32u;   // conv: NHWC or GROUP
+            for (int slot = 0; slot < 3; slot++) {
+                const PieceSrc ps = piece_src(im, slot * 4 + w, lane, Y0 - 1, X0 - 1, 2, pl >> 1, pl & 1, IW, IH);
+                poff[pl][slot] = ps.ok ? ps.off : OOB;
+            }
+        const uint32_t qstride = im.grp;   // next channel group
         // ---- prologue: planes 0..2 of group 0 (plane 3 arrives in steps 1..3) + PF16 weight tiles -
 #pragma unroll
         for (int pl = 0; pl < 3; pl++)
@@ -291,7 +319,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
 #pragma unroll 1
         for (int q0 = 0; q0 < NQ; q0 += 2) conv_passes16<NT16, 0>(acc, ctx, poff, q0, qstride);
         wait_vmcnt<0>();
-        store_tiles16<NT16>(acc, out_img, OW, OH, MW, MH, Y0, X0, w, pos, g, false, 0, 0, out_layout);
+        store_tiles16<NT16>(acc, out_img, out_img_bytes, om, MW, MH, Y0, X0, w, pos, g, false, 0, 0);
     }
 }
 
