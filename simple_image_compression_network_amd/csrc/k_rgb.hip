@@ -227,8 +227,10 @@ hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
     const int tiles_x = (g.OW + TILE_X - 1) / TILE_X, tiles_y = (g.OH + L0_TY - 1) / L0_TY;
     // runs of at most L0_CHUNK tiles (the LDS holds a run's pixels), evened out; the test hook can only shorten them
     int y_chunks = (tiles_y + L0_CHUNK - 1) / L0_CHUNK;
+    int want = (1024 + tiles_x * n_images - 1) / (tiles_x * n_images);   // small images: shorter runs, enough workgroups
     const int forced = strip_chunks_override();
-    if (forced > y_chunks) y_chunks = forced > tiles_y ? tiles_y : forced;
+    if (forced > 0) want = forced;
+    if (want > y_chunks) y_chunks = want > tiles_y ? tiles_y : want;
     const int ty_per = (tiles_y + y_chunks - 1) / y_chunks;
     y_chunks = (tiles_y + ty_per - 1) / ty_per;
     dim3 grid((unsigned)tiles_x, (unsigned)y_chunks, (unsigned)n_images);
@@ -449,7 +451,9 @@ __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ 
             }
             wait_vmcnt<0>();
         }
+#ifndef SICN_EXP_L7_NO_BARRIER   // timing experiment only (races)
         block_barrier();   // next rows landed for every wave, this step's rows are free
+#endif
         base += L7_ROWS * L7_PITCH;
         base = base >= L7_RING_POS ? base - L7_RING_POS : base;
         pnext += L7_STEP_PIECES;

@@ -18,9 +18,11 @@ ap.add_argument("envvar")
 ap.add_argument("values", nargs="+")
 ap.add_argument("--rounds", type=int, default=8)
 ap.add_argument("--images", type=int, default=8)
+ap.add_argument("--width", type=int, default=3840)
+ap.add_argument("--height", type=int, default=2160)
 args = ap.parse_args()
 
-W, H, B = 3840, 2160, args.images
+W, H, B = args.width, args.height, args.images
 x = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (B, H, W, 3), dtype=np.uint8)).cuda()
 net = api.EightLayersNet(W, H)
 out = torch.empty((B,) + net.descs[-1].out_shape, dtype=torch.uint8, device="cuda")
