@@ -108,6 +108,34 @@ def test_strip_kernels_long_strips(api, case, chunks, monkeypatch):
         assert np.array_equal(got[i], ref), f"image {i}: {np.count_nonzero(got[i] != ref)} bytes differ"
 
 
+MFMA_CASES = [c for c in SPECIAL if c[0] != 3 and c[1] != 3]
+
+
+@pytest.mark.parametrize("case", MFMA_CASES)
+def test_32x32x32_kernels_match_oracle(api, case, monkeypatch):
+    """k_mfma.hip (v_mfma_i32_32x32x32_i8) is kept as a second implementation of L1-L6, selected per launch
+    by SICN_MFMA_SHAPE=32: it must stay bit-exact too, standalone and inside a chain (internal layouts)."""
+    monkeypatch.setenv("SICN_MFMA_SHAPE", "32")
+    rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + 5)
+    d = _mk_desc(*case)
+    W, b, words = _rand_params(rng, d)
+    x = rng.integers(0, 128, (2,) + d.in_shape, dtype=np.uint8)
+    got = _run_layer(api, d, words, b, x)
+    ref_fn = sicn_ref.deconv522_ref if d.transposed else sicn_ref.conv2d_ref
+    for i in range(2):
+        assert np.array_equal(got[i], ref_fn(x[i], W, b))
+
+
+def test_32x32x32_kernels_in_chain(api, monkeypatch):
+    monkeypatch.setenv("SICN_MFMA_SHAPE", "32")
+    xin = _dev(_input("rng256")[None])
+    net = api.EightLayersNet(256, 256)
+    out, latent = net.forward(xin)
+    torch.cuda.synchronize()
+    assert _sha(out[0].cpu().numpy()) == HASHES["layers"]["rng256"][7]
+    assert _sha(latent[0].cpu().numpy()) == HASHES["layers"]["rng256"][3]
+
+
 def test_specialised_and_generic_kernels_agree(api):
     from simple_image_compression_network_amd import _lib
     L = _lib.lib()
