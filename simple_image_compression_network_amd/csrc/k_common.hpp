@@ -111,30 +111,45 @@ __device__ __forceinline__ uint32_t piece_src_offset(int k, int lane, int Yb, in
     return ok ? tensor_offset(layout, iy, ix, g, C, IW, IH) + hlog * 16 : OOB;
 }
 
+// Tile geometry of the 16x16x64 kernels: TILE_Y x TX positions (TX = 32, or 16 for the layers whose
+// accumulators / patch allow only one 8 x 32 workgroup per CU), sub-patch of (TILE_Y+2) x (TX+2)
+// positions x 32 B, padded to SLOTS pieces per wave so that every wave issues the same number.
+template <int TX>
+struct Geo {
+    static constexpr int PX = TX + 2;                              // patch row pitch in positions
+    static constexpr int PIX = PATCH_Y * PX;                       // 340 / 180 positions
+    static constexpr int SLOTS = (PIX * KSTEP + 4095) / 4096;      // LDS-DMA pieces per wave per sub-patch: 3 / 2
+    static constexpr int ALLOC = SLOTS * 4 * 1024;                 // 12288 / 8192
+    static constexpr int XT = TX / 16;                             // 16-position column tiles per row
+    static constexpr int NC = 2 * XT;                              // column tiles per wave (2 rows)
+};
+
 // The same with the layout as strides: patch position and validity of this lane in piece `k`
 // (unswizzled image, 16x16x64 kernels), channel group 0; group g is `+ g * tm.grp`.
 struct PieceSrc {
     uint32_t off;   // byte offset of channel group 0 (meaningless if !ok)
     bool ok;
 };
+template <int TX>
 __device__ __forceinline__ PieceSrc piece_src(const TensorMap &tm, int k, int lane, int Yb, int Xb, int s, int ay, int ax,
                                               int IW, int IH)
 {
     const int p = k * 32 + (lane >> 1);
-    const int ty = p / PATCH_X, tx = p - ty * PATCH_X;
+    const int ty = p / Geo<TX>::PX, tx = p - ty * Geo<TX>::PX;
     const int iy = s * (Yb + ty) + ay, ix = s * (Xb + tx) + ax;
     PieceSrc r;
-    r.ok = p < PATCH_PIX && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
+    r.ok = p < Geo<TX>::PIX && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
     r.off = tensor_offset(tm, iy, ix, 0u) + (uint32_t)(lane & 1) * 16u;
     return r;
 }
 
-// one LDS-DMA piece (1 KiB) of sub-patch `sub`
+// one LDS-DMA piece (1 KiB) of sub-patch `sub` (sub-patches are ALLOC bytes apart)
+template <int ALLOC = SUB_ALLOC>
 __device__ __forceinline__ void load_piece(uint8_t *patch, const uint8_t *in_img, int in_img_bytes, int sub,
                                            int k, uint32_t off)
 {
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)in_img, 0, in_img_bytes, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(patch + sub * SUB_ALLOC + k * 1024), 16, off, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(patch + sub * ALLOC + k * 1024), 16, off, 0, 0, 0);
 }
 
 // XCD-aware work mapping.  Workgroups of a 1-D grid are dealt to the 8 XCDs round-robin (linear id % 8)

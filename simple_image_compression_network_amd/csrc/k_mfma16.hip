@@ -10,8 +10,8 @@
 //   conv  : A, B = two consecutive taps of the plane-ordered walk (possibly two different planes)
 //   deconv: A, B = channel groups q, q+1 of the same tap
 // Lane roles (l = lane): pos/row = l & 15, g = l >> 4: step = g >> 1, 16-byte half = g & 1.
-//   pixel fragment c (4 per wave: row i = c >> 1 of the wave's two rows, x half c & 1):
-//       16 bytes at patch[sub_step][(2w + i + oy_step) * 34 + 16*(c&1) + pos + ox_step][half]
+//   pixel fragment c (NC = 2 * TX/16 per wave: row i = c / (TX/16) of the wave's two rows, column tile c % (TX/16)):
+//       16 bytes at patch[sub_step][(2w + i + oy_step) * (TX+2) + 16*(c % (TX/16)) + pos + ox_step][half]
 //   weight fragment j (COUT/16 per pass): 16 bytes at ring[step][row j*16 + pos][half]
 // Neither image is swizzled: the hardware's 16-lane ds_read_b128 groups pair positions {0-3,12-15}
 // of one half with positions {4-11} of the other, which already covers 16 distinct 16-byte slots.
@@ -57,8 +57,8 @@ __device__ __forceinline__ void load_wtile16(uint8_t *ring, const int8_t *wstrea
 }
 
 // accumulators start at the bias: register r of tile (c, j) is channel 64*(j>>2) + 16g + 4*(j&3) + r
-template <int NT16>
-__device__ __forceinline__ void init_acc16(v4i (&acc)[4][NT16], const int8_t *bias, int g)
+template <int NT16, int NC>
+__device__ __forceinline__ void init_acc16(v4i (&acc)[NC][NT16], const int8_t *bias, int g)
 {
 #pragma unroll
     for (int J = 0; J < NT16 / 4; J++) {
@@ -69,7 +69,7 @@ __device__ __forceinline__ void init_acc16(v4i (&acc)[4][NT16], const int8_t *bi
 #pragma unroll
             for (int r = 0; r < 4; r++) v[r] = (int)(int8_t)((uint32_t)b4[jj] >> (8 * r));
 #pragma unroll
-            for (int c = 0; c < 4; c++) acc[c][4 * J + jj] = v;
+            for (int c = 0; c < NC; c++) acc[c][4 * J + jj] = v;
         }
     }
 }
@@ -81,13 +81,14 @@ __device__ __forceinline__ void init_acc16(v4i (&acc)[4][NT16], const int8_t *bi
 //   wt_off  : byte offset of this lane's fragment 0 inside the ring, including the step's slot
 //   FIRST   : the accumulators start here: C operand = the bias (unpacked per weight tile into 4
 //             scratch registers) instead of 4 * NT16 * 4 register initialisations before the pass
-template <int NT16, int VMCNT, int EXTRA, bool FIRST = false>
-__device__ __forceinline__ void pass16(v4i (&acc)[4][NT16], const uint8_t *patch, const uint8_t *ring, uint32_t pix_off,
+template <int TX, int NT16, int VMCNT, int EXTRA, bool FIRST = false>
+__device__ __forceinline__ void pass16(v4i (&acc)[Geo<TX>::NC][NT16], const uint8_t *patch, const uint8_t *ring, uint32_t pix_off,
                                        uint32_t wt_off, bool extra, const v4i (&bias4)[NT16 / 4] = {})
 {
-    v4i pf[4], wf[NT16];
+    constexpr int NC = Geo<TX>::NC, XT = Geo<TX>::XT;
+    v4i pf[NC], wf[NT16];
 #pragma unroll
-    for (int c = 0; c < 4; c++) pf[c] = *(const v4i *)(patch + pix_off + ((c >> 1) * PATCH_X + (c & 1) * 16) * 32);
+    for (int c = 0; c < NC; c++) pf[c] = *(const v4i *)(patch + pix_off + ((c / XT) * Geo<TX>::PX + (c % XT) * 16) * 32);
 #pragma unroll
     for (int j = 0; j < NT16; j++) wf[j] = *(const v4i *)(ring + wt_off + j * 16 * 32);
 #pragma unroll
@@ -98,12 +99,12 @@ __device__ __forceinline__ void pass16(v4i (&acc)[4][NT16], const uint8_t *patch
             for (int r = 0; r < 4; r++) cin[r] = (int)(int8_t)((uint32_t)bias4[j >> 2][j & 3] >> (8 * r));
         }
 #pragma unroll
-        for (int c = 0; c < 4; c++)
+        for (int c = 0; c < NC; c++)
             acc[c][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[j], pf[c], FIRST ? cin : acc[c][j], 0, 0, 0);
     }
 #ifndef SICN_NO_SCHED16
-    __builtin_amdgcn_sched_group_barrier(0x100, 4 + NT16, 0);   // all fragment reads first
-    if constexpr (!FIRST) __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT16, 0);   // then the MFMA cluster
+    __builtin_amdgcn_sched_group_barrier(0x100, NC + NT16, 0);   // all fragment reads first
+    if constexpr (!FIRST) __builtin_amdgcn_sched_group_barrier(0x008, NC * NT16, 0);   // then the MFMA cluster
 #endif
 #ifdef SICN_EXP_NOWAIT   // timing experiment only (results are wrong): never block on vmcnt inside the loop
     wait_vmcnt<63>();
@@ -116,16 +117,18 @@ __device__ __forceinline__ void pass16(v4i (&acc)[4][NT16], const uint8_t *patch
     block_barrier();
 }
 
-// Always issues 4 * NT16/4 stores per wave (positions outside the image go to an out-of-range offset
+// Always issues NC * NT16/4 stores per wave (positions outside the image go to an out-of-range offset
 // of a buffer descriptor, which drops them): the counted waits of the following passes rely on it.
-template <int NT16>
-__device__ __forceinline__ void store_tiles16(const v4i (&acc)[4][NT16], uint8_t *out_img, int out_img_bytes, const TensorMap &om,
-                                              int MW, int MH, int Y0, int X0, int w, int pos, int g, bool deconv, int py, int px)
+template <int TX, int NT16>
+__device__ __forceinline__ void store_tiles16(const v4i (&acc)[Geo<TX>::NC][NT16], uint8_t *out_img, int out_img_bytes,
+                                              const TensorMap &om, int MW, int MH, int Y0, int X0, int w, int pos, int g,
+                                              bool deconv, int py, int px)
 {
+    constexpr int NC = Geo<TX>::NC, XT = Geo<TX>::XT;
     __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)out_img, 0, out_img_bytes, 0x00020000);
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const int gy = Y0 + 2 * w + (c >> 1), gx = X0 + (c & 1) * 16 + pos;
+    for (int c = 0; c < NC; c++) {
+        const int gy = Y0 + 2 * w + c / XT, gx = X0 + (c % XT) * 16 + pos;
         const bool ok = gy < MH && gx < MW;
         const int oy_ = deconv ? 2 * gy + py : gy, ox_ = deconv ? 2 * gx + px : gx;
         // channels 64J + 16g .. +15 = channel group 2J + (g>>1), second half iff g odd
@@ -142,15 +145,23 @@ __device__ __forceinline__ void store_tiles16(const v4i (&acc)[4][NT16], uint8_t
     }
 }
 
-// conv: refresh schedule of the 4 parity planes in a 25-step channel group.  A plane may only be
-// re-filled from the pass AFTER the one that holds its last read, whatever the step parity of the
-// group is, i.e. from (last read step + 2): plane 0 (last read 8) at steps 10..12, plane 1 (14) at
-// 16..18, plane 2 (20) at 22..24, plane 3 (24) at steps 1..3 of the NEXT group.
-__host__ __device__ constexpr int refresh16_plane(int t)
+// conv: refresh schedule of the 4 parity planes in a 25-step channel group, S = Geo::SLOTS steps per
+// plane (one piece per wave and step).  A plane may only be re-filled from the pass AFTER the one that
+// holds its last read, whatever the step parity of the group is, i.e. from (last read step + 2):
+// plane 0 (last read 8) from step 10, plane 1 (14) from 16, plane 2 (20) from 22, plane 3 (24) from
+// step 1 of the NEXT group.
+__host__ __device__ constexpr int refresh16_start(int plane) { return plane == 3 ? 1 : plane == 0 ? 10 : plane == 1 ? 16 : 22; }
+__host__ __device__ constexpr int refresh16_plane(int t, int S)
 {
-    return (t >= 1 && t < 4) ? 3 : (t >= 10 && t < 13) ? 0 : (t >= 16 && t < 19) ? 1 : (t >= 22 && t < 25) ? 2 : -1;
+    for (int pl = 0; pl < 4; pl++)
+        if (t >= refresh16_start(pl) && t < refresh16_start(pl) + S) return pl;
+    return -1;
 }
-__host__ __device__ constexpr int refresh16_slot(int t) { return t < 4 ? t - 1 : t < 13 ? t - 10 : t < 19 ? t - 16 : t - 22; }
+__host__ __device__ constexpr int refresh16_slot(int t, int S)
+{
+    const int pl = refresh16_plane(t, S);
+    return pl < 0 ? 0 : t - refresh16_start(pl);
+}
 
 struct Conv16Ctx {
     uint8_t *patch;
@@ -164,10 +175,11 @@ struct Conv16Ctx {
 };
 
 // pass P of a 50-step window (two channel groups q0, q0+1): steps 2P, 2P+1
-template <int NT16, int P>
-__device__ __forceinline__ void conv_passes16(v4i (&acc)[4][NT16], const Conv16Ctx &c, const uint32_t (&poff)[4][3], int q0,
-                                              uint32_t qstride)
+template <int TX, int NT16, int P>
+__device__ __forceinline__ void conv_passes16(v4i (&acc)[Geo<TX>::NC][NT16], const Conv16Ctx &c,
+                                              const uint32_t (&poff)[4][Geo<TX>::SLOTS], int q0, uint32_t qstride)
 {
+    constexpr int PATCH_X = Geo<TX>::PX, SUB_ALLOC = Geo<TX>::ALLOC, S = Geo<TX>::SLOTS;   // this tile width's geometry
     constexpr int TB = NT16 * 16 * KSTEP, WR = (TB / 1024 + 3) / 4;
     constexpr int SA = 2 * P, SB = 2 * P + 1;              // steps inside the 50-step window
     constexpr int TA = SA % 25, TBs = SB % 25;             // tap index inside the channel group
@@ -178,15 +190,15 @@ __device__ __forceinline__ void conv_passes16(v4i (&acc)[4][NT16], const Conv16C
     const int qA = q0 + SA / 25, qB = q0 + SB / 25;
     const int stepA = qA * 25 + TA, stepB = qB * 25 + TBs;   // = stepA + 1
     // (1) plane refresh pieces scheduled for these two steps
-    constexpr int rpA = refresh16_plane(TA), rpB = refresh16_plane(TBs);
+    constexpr int rpA = refresh16_plane(TA, S), rpB = refresh16_plane(TBs, S);
     if constexpr (rpA >= 0) {
-        constexpr int slot = refresh16_slot(TA);
-        load_piece(c.patch, c.in_img, c.in_img_bytes, rpA, slot * 4 + c.w,
+        constexpr int slot = refresh16_slot(TA, S);
+        load_piece<SUB_ALLOC>(c.patch, c.in_img, c.in_img_bytes, rpA, slot * 4 + c.w,
                    poff[rpA][slot] + (uint32_t)((rpA == 3) ? qA : qA + 1) * qstride);
     }
     if constexpr (rpB >= 0) {
-        constexpr int slot = refresh16_slot(TBs);
-        load_piece(c.patch, c.in_img, c.in_img_bytes, rpB, slot * 4 + c.w,
+        constexpr int slot = refresh16_slot(TBs, S);
+        load_piece<SUB_ALLOC>(c.patch, c.in_img, c.in_img_bytes, rpB, slot * 4 + c.w,
                    poff[rpB][slot] + (uint32_t)((rpB == 3) ? qB : qB + 1) * qstride);
     }
     // (2) weight tiles of the pass after next (the stream is padded with PF16 zero tiles)
@@ -199,12 +211,12 @@ __device__ __forceinline__ void conv_passes16(v4i (&acc)[4][NT16], const Conv16C
     // window's last pass for P == 0; before the first window nothing is outstanding, which only helps)
     constexpr int TPa = (SA + 48) % 25, TPb = (SA + 49) % 25;
     constexpr int own = 2 * WR + (rpA >= 0) + (rpB >= 0);
-    constexpr int prev = 2 * WR + (refresh16_plane(TPa) >= 0) + (refresh16_plane(TPb) >= 0);
-    pass16<NT16, own + (WAITP - 1) * prev, 0>(acc, c.patch, c.ring, pix, wt, false);
-    if constexpr (P + 1 < 25) conv_passes16<NT16, P + 1>(acc, c, poff, q0, qstride);
+    constexpr int prev = 2 * WR + (refresh16_plane(TPa, S) >= 0) + (refresh16_plane(TPb, S) >= 0);
+    pass16<TX, NT16, own + (WAITP - 1) * prev, 0>(acc, c.patch, c.ring, pix, wt, false);
+    if constexpr (P + 1 < 25) conv_passes16<TX, NT16, P + 1>(acc, c, poff, q0, qstride);
 }
 
-template <int NQ, int NT16, bool DECONV, int MINW>
+template <int NQ, int NT16, bool DECONV, int MINW, int TX>
 __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
     const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int8_t *__restrict__ wstream,
     const int8_t *__restrict__ bias, int IW, int IH, int OW, int OH, int MW, int MH, int tiles_x, int n_tiles, int n_images,
@@ -214,6 +226,8 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
     constexpr int CIN = NQ * 32, COUT = NT16 * 16;
     constexpr int NSUB = DECONV ? NQ : 4;
     constexpr int TB = COUT * KSTEP, WR = (TB / 1024 + 3) / 4;
+    constexpr int PATCH_X = Geo<TX>::PX, SUB_ALLOC = Geo<TX>::ALLOC, SLOTS = Geo<TX>::SLOTS, NC = Geo<TX>::NC;
+    constexpr int NSTORE = NC * NT16 / 4;   // output stores per wave and tile (phase)
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *patch = smem;
@@ -228,7 +242,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
     if (item < 0) return;   // before any LDS-DMA is issued
     const int img = item / n_tiles, tile = item - img * n_tiles;
     const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
-    const int Y0 = tile_y * TILE_Y, X0 = tile_x * TILE_X;
+    const int Y0 = tile_y * TILE_Y, X0 = tile_x * TX;
 
     const int in_img_bytes = IH * IW * CIN;
     const uint8_t *in_img = in + (size_t)img * in_img_bytes;
@@ -239,16 +253,16 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
     const TensorMap im = tensor_map(in_layout, CIN, IW, IH), om = tensor_map(out_layout, COUT, OW, OH);
     const int out_img_bytes = OH * OW * COUT;
 
-    v4i acc[4][NT16];
+    v4i acc[NC][NT16];
 
     if constexpr (DECONV) {
         // ---- prologue: the whole patch (NQ channel groups) + PF16 weight tiles -------------------
 #pragma unroll
-        for (int slot = 0; slot < 3; slot++) {
-            const PieceSrc ps = piece_src(im, slot * 4 + w, lane, Y0 - 1, X0 - 1, 1, 0, 0, IW, IH);
+        for (int slot = 0; slot < SLOTS; slot++) {
+            const PieceSrc ps = piece_src<TX>(im, slot * 4 + w, lane, Y0 - 1, X0 - 1, 1, 0, 0, IW, IH);
 #pragma unroll
             for (int sub = 0; sub < NQ; sub++)
-                load_piece(patch, in_img, in_img_bytes, sub, slot * 4 + w, ps.ok ? ps.off + (uint32_t)sub * im.grp : OOB);
+                load_piece<SUB_ALLOC>(patch, in_img, in_img_bytes, sub, slot * 4 + w, ps.ok ? ps.off + (uint32_t)sub * im.grp : OOB);
         }
 #pragma unroll
         for (int s = 0; s < PF16; s++) load_wtile16<TB>(ring, wstream, s, lane, w);
@@ -277,7 +291,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
                     load_wtile16<TB>(ring, wstream, step + 1 + PF16, lane, w);
                     const uint32_t pix = lane_pix + tap_off + (uint32_t)(hi * SUB_ALLOC);
                     const uint32_t wt = lane_wt + (uint32_t)(((step + hi) % RING16) * TB);
-                    pass16<NT16, 2 * WR * WAITP, NT16, true>(acc, patch, ring, pix, wt, ph > 0, bias4);
+                    pass16<TX, NT16, 2 * WR * WAITP, NSTORE, true>(acc, patch, ring, pix, wt, ph > 0, bias4);
                     q0 = 2;
                 }
 #pragma unroll NQ <= 4 ? 2 : 1
@@ -286,21 +300,21 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
                     load_wtile16<TB>(ring, wstream, step + q + 1 + PF16, lane, w);
                     const uint32_t pix = lane_pix + tap_off + (uint32_t)((q + hi) * SUB_ALLOC);
                     const uint32_t wt = lane_wt + (uint32_t)(((step + q + hi) % RING16) * TB);
-                    pass16<NT16, 2 * WR * WAITP, NT16>(acc, patch, ring, pix, wt, ph > 0 && t == 0 && q < 2 * WAITP);
+                    pass16<TX, NT16, 2 * WR * WAITP, NSTORE>(acc, patch, ring, pix, wt, ph > 0 && t == 0 && q < 2 * WAITP);
                 }
                 step += NQ;
             }
             if (ph == 3) wait_vmcnt<0>();  // the padded tail of the weight prefetch must land before exit
-            store_tiles16<NT16>(acc, out_img, out_img_bytes, om, MW, MH, Y0, X0, w, pos, g, true, py, px);
+            store_tiles16<TX, NT16>(acc, out_img, out_img_bytes, om, MW, MH, Y0, X0, w, pos, g, true, py, px);
         }
     } else {
         // ---- per-lane source offsets of the 4 planes x 3 refresh slots (channel group 0) --------
-        uint32_t poff[4][3];
+        uint32_t poff[4][SLOTS];
 #pragma unroll
         for (int pl = 0; pl < 4; pl++)
 #pragma unroll
-            for (int slot = 0; slot < 3; slot++) {
-                const PieceSrc ps = piece_src(im, slot * 4 + w, lane, Y0 - 1, X0 - 1, 2, pl >> 1, pl & 1, IW, IH);
+            for (int slot = 0; slot < SLOTS; slot++) {
+                const PieceSrc ps = piece_src<TX>(im, slot * 4 + w, lane, Y0 - 1, X0 - 1, 2, pl >> 1, pl & 1, IW, IH);
                 poff[pl][slot] = ps.ok ? ps.off : OOB;
             }
         const uint32_t qstride = im.grp;   // next channel group
@@ -308,47 +322,71 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
 #pragma unroll
         for (int pl = 0; pl < 3; pl++)
 #pragma unroll
-            for (int slot = 0; slot < 3; slot++) load_piece(patch, in_img, in_img_bytes, pl, slot * 4 + w, poff[pl][slot]);
+            for (int slot = 0; slot < SLOTS; slot++) load_piece<SUB_ALLOC>(patch, in_img, in_img_bytes, pl, slot * 4 + w, poff[pl][slot]);
 #pragma unroll
         for (int s = 0; s < PF16; s++) load_wtile16<TB>(ring, wstream, s, lane, w);
         wait_vmcnt<0>();
         block_barrier();
 
         const Conv16Ctx ctx{patch, ring, wstream, in_img, in_img_bytes, lane_pix, lane_wt, lane, w, hi};
-        init_acc16<NT16>(acc, bias, g);
+        init_acc16<NT16, NC>(acc, bias, g);
 #pragma unroll 1
-        for (int q0 = 0; q0 < NQ; q0 += 2) conv_passes16<NT16, 0>(acc, ctx, poff, q0, qstride);
+        for (int q0 = 0; q0 < NQ; q0 += 2) conv_passes16<TX, NT16, 0>(acc, ctx, poff, q0, qstride);
         wait_vmcnt<0>();
-        store_tiles16<NT16>(acc, out_img, out_img_bytes, om, MW, MH, Y0, X0, w, pos, g, false, 0, 0);
+        store_tiles16<TX, NT16>(acc, out_img, out_img_bytes, om, MW, MH, Y0, X0, w, pos, g, false, 0, 0);
     }
 }
 
-#define SICN_INST16(NQ, NT16, D)                                                                                 \
-    template __global__ void k_mfma16_t<NQ, NT16, D, ((NT16 <= 8 && NQ <= 4) ? 2 : 1)>(                           \
+// workgroups per CU the registers / LDS of a variant allow: 8 x 32 tiles of the 192-channel layers only 1
+constexpr int minw16(int NQ, int NT16, int TX) { return (TX == 16 || (NT16 <= 8 && NQ <= 4)) ? 2 : 1; }
+
+#define SICN_INST16(NQ, NT16, D, TX)                                                                             \
+    template __global__ void k_mfma16_t<NQ, NT16, D, minw16(NQ, NT16, TX), TX>(                                    \
         const uint8_t *__restrict__, uint8_t *__restrict__, const int8_t *__restrict__, const int8_t *__restrict__, \
         int, int, int, int, int, int, int, int, int, int, int);
-SICN_INST16(4, 8, true)
-SICN_INST16(6, 8, true)
-SICN_INST16(4, 8, false)
-SICN_INST16(4, 12, false)
+SICN_INST16(4, 8, true, 32)
+SICN_INST16(6, 8, true, 32)
+SICN_INST16(4, 8, false, 32)
+SICN_INST16(4, 12, false, 32)
+SICN_INST16(4, 8, true, 16)
+SICN_INST16(6, 8, true, 16)
+SICN_INST16(4, 8, false, 16)
+SICN_INST16(4, 12, false, 16)
 #undef SICN_INST16
 
+template <int NQ, int NT16, bool DECONV, int TX>
+static hipError_t launch16_tx(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
+                              hipStream_t stream, int in_layout, int out_layout)
+{
+    constexpr int NSUB = DECONV ? NQ : 4;
+    constexpr int MINW = minw16(NQ, NT16, TX);
+    const int MW = DECONV ? g.IW : g.OW, MH = DECONV ? g.IH : g.OH;
+    const int tiles_x = (MW + TX - 1) / TX, tiles_y = (MH + TILE_Y - 1) / TILE_Y;
+    const size_t lds = (size_t)NSUB * Geo<TX>::ALLOC + (size_t)RING16 * NT16 * 16 * KSTEP;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mfma16_t<NQ, NT16, DECONV, MINW, TX>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    dim3 grid(xcd_grid_size(tiles_x * tiles_y * n_images));
+    hipLaunchKernelGGL((k_mfma16_t<NQ, NT16, DECONV, MINW, TX>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias,
+                       g.IW, g.IH, g.OW, g.OH, MW, MH, tiles_x, tiles_x * tiles_y, n_images, in_layout, out_layout);
+    return hipGetLastError();
+}
+
+// Tile width: 8 x 32 positions by default; 8 x 16 where the wide tile allows only one workgroup per CU
+// (the 192-channel layers) or leaves most of the chip without a tile (small images).  SICN_TILE_X=16|32
+// forces one (experiments, tests; read per launch).
 template <int NQ, int NT16, bool DECONV>
 static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
                            hipStream_t stream, int in_layout, int out_layout)
 {
-    constexpr int NSUB = DECONV ? NQ : 4;
-    constexpr int MINW = ((NT16 <= 8 && NQ <= 4) ? 2 : 1);
     const int MW = DECONV ? g.IW : g.OW, MH = DECONV ? g.IH : g.OH;
-    const int tiles_x = (MW + TILE_X - 1) / TILE_X, tiles_y = (MH + TILE_Y - 1) / TILE_Y;
-    const size_t lds = (size_t)NSUB * SUB_ALLOC + (size_t)RING16 * NT16 * 16 * KSTEP;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mfma16_t<NQ, NT16, DECONV, MINW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    dim3 grid(xcd_grid_size(tiles_x * tiles_y * n_images));
-    hipLaunchKernelGGL((k_mfma16_t<NQ, NT16, DECONV, MINW>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias,
-                       g.IW, g.IH, g.OW, g.OH, MW, MH, tiles_x, tiles_x * tiles_y, n_images, in_layout, out_layout);
-    return hipGetLastError();
+    const long tiles32 = (long)((MW + 31) / 32) * ((MH + TILE_Y - 1) / TILE_Y) * n_images;
+    bool narrow = minw16(NQ, NT16, 32) == 1 || tiles32 < 2 * 256;
+    const char *e = getenv("SICN_TILE_X");
+    if (e && e[0] == '1') narrow = true;
+    if (e && e[0] == '3') narrow = false;
+    return narrow ? launch16_tx<NQ, NT16, DECONV, 16>(g, w, in, out, n_images, stream, in_layout, out_layout)
+                  : launch16_tx<NQ, NT16, DECONV, 32>(g, w, in, out, n_images, stream, in_layout, out_layout);
 }
 
 hipError_t launch_mfma16(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,

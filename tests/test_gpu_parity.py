@@ -126,6 +126,33 @@ def test_32x32x32_kernels_match_oracle(api, case, monkeypatch):
         assert np.array_equal(got[i], ref_fn(x[i], W, b))
 
 
+@pytest.mark.parametrize("tile_x", ["16", "32"])
+@pytest.mark.parametrize("case", MFMA_CASES + [(128, 128, 8, 16, 50, 20, 0), (192, 128, 12, 16, 37, 21, 1), (128, 192, 8, 24, 47, 18, 0)])
+def test_both_tile_widths_match_oracle(api, case, tile_x, monkeypatch):
+    """The 16x16x64 kernels exist for 8 x 32 and 8 x 16 position tiles (the launcher picks by layer shape and
+    grid size); force each one on every shape."""
+    monkeypatch.setenv("SICN_TILE_X", tile_x)
+    rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + int(tile_x))
+    d = _mk_desc(*case)
+    W, b, words = _rand_params(rng, d)
+    x = rng.integers(0, 128, (2,) + d.in_shape, dtype=np.uint8)
+    got = _run_layer(api, d, words, b, x)
+    ref_fn = sicn_ref.deconv522_ref if d.transposed else sicn_ref.conv2d_ref
+    for i in range(2):
+        assert np.array_equal(got[i], ref_fn(x[i], W, b))
+
+
+@pytest.mark.parametrize("tile_x", ["16", "32"])
+def test_both_tile_widths_in_chain(api, tile_x, monkeypatch):
+    monkeypatch.setenv("SICN_TILE_X", tile_x)
+    xin = _dev(_input("rng768")[None])
+    net = api.EightLayersNet(768, 512)
+    out, latent = net.forward(xin)
+    torch.cuda.synchronize()
+    assert _sha(out[0].cpu().numpy()) == HASHES["layers"]["rng768"][7]
+    assert _sha(latent[0].cpu().numpy()) == HASHES["layers"]["rng768"][3]
+
+
 def test_32x32x32_kernels_in_chain(api, monkeypatch):
     monkeypatch.setenv("SICN_MFMA_SHAPE", "32")
     xin = _dev(_input("rng256")[None])
