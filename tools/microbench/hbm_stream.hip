@@ -30,6 +30,33 @@ __global__ __launch_bounds__(256) void k_read_dma(const uint8_t *in, size_t byte
     if (sink && smem[threadIdx.x] == 0x77 && bytes == 1) *sink = 1;
 }
 
+// L7-like: a workgroup walks a strip; per step it reads `nruns` runs of `run` bytes, run r of step t at
+//   plane(r) * plane_stride + (t * rows_per_step + row(r)) * row_pitch + strip * run
+// (planes x rows per step = nruns; neighbouring workgroups read neighbouring runs of the same rows)
+__global__ __launch_bounds__(256) void k_read_runs(const uint8_t *in, size_t plane_stride, int row_pitch, int planes, int rows_per_step,
+                                                   int run, int steps, int strips, int *sink)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int strip = blockIdx.x % strips, chunk = blockIdx.x / strips;
+    const int nruns = planes * rows_per_step, lanes_per_run = run / 16, total = nruns * lanes_per_run;
+    for (int t = 0; t < steps; t++) {
+        const int row0 = (chunk * steps + t) * rows_per_step;
+        for (int i = w * 64 + lane, k = w; i < total + 63; i += 256, k += 4) {
+            const int ii = i < total ? i : total - 1;
+            const int r = ii / lanes_per_run, o = ii - r * lanes_per_run;
+            const int pl = r % planes, row = r / planes;
+            const uint8_t *src = in + (size_t)pl * plane_stride + (size_t)(row0 + row) * row_pitch + (size_t)strip * run + o * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             LDS_PTR(smem + ((t & 1) * 20 + k) * 1024), 16, 0, 0);
+            if (i - lane + 64 >= total + 63) break;
+        }
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // one step (<= 5 loads per wave) stays in flight
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (sink && smem[threadIdx.x] == 0x77 && steps == -1) *sink = 1;
+}
+
 // plain 16-byte loads into registers, xor-reduced
 __global__ __launch_bounds__(256) void k_read_reg(const uint4 *in, size_t n16, int *sink)
 {
@@ -97,6 +124,30 @@ int main()
         timeit(nm, [&] { hipLaunchKernelGGL(k_read_reg, dim3(wgs), dim3(256), 0, 0, (const uint4 *)buf, bytes / 16, sink); });
         snprintf(nm, 96, "write linear 16B/lane             %4d WGs", wgs);
         timeit(nm, [&] { hipLaunchKernelGGL(k_write, dim3(wgs), dim3(256), 0, 0, (uint4 *)buf, bytes / 16, 7u); });
+    }
+    {
+        // 2.12 GB as `planes` planes of 1080*1920*128/planes bytes; a step = 4 rows of a 32-position strip
+        struct Cfg { const char *name; int planes, run, rows_per_step; } cfgs[] = {
+            {"read  runs NHWC    1 plane  x 4352 B x 4 rows", 1, 4352, 4}, {"read  runs GROUP   4 planes x 1088 B x 4 rows", 4, 1088, 4},
+            {"read  runs PHASE  16 planes x  544 B x 2 rows", 16, 544, 2}, {"read  runs PHASE  16 planes x 1088 B x 2 rows (64-wide strips, 2 steps)", 16, 1088, 2},
+            {"read  runs         2 planes x 2176 B x 4 rows", 2, 2176, 4}};
+        for (auto &c : cfgs) {
+            const int strips = 60, steps = 20;
+            const int row_pitch = strips * c.run;                    // runs of neighbouring strips are adjacent
+            const int rows_total = (int)(bytes / ((size_t)c.planes * row_pitch)) / (c.rows_per_step * steps) * (c.rows_per_step * steps);
+            const size_t plane_stride = (size_t)row_pitch * rows_total;   // planes * plane_stride <= bytes
+            const int chunks = rows_total / (c.rows_per_step * steps);
+            float best = 1e9f;
+            for (int r = 0; r < 5; r++) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(k_read_runs, dim3(strips * chunks), dim3(256), 40960, 0, buf, plane_stride, row_pitch, c.planes,
+                                   c.rows_per_step, c.run, steps, strips, sink);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+            }
+            const double moved = (double)strips * chunks * steps * c.planes * c.rows_per_step * c.run;
+            printf("%-72s %7.3f ms  %6.2f TB/s  (%.2f GB)\n", c.name, best, moved / best / 1e9, moved / 1e9);
+        }
     }
     for (int yc : {1, 5, 9, 27}) {
         char nm[96];
