@@ -94,7 +94,16 @@ def main():
     # synthetic inputs: uint8 NHWC, i.i.d. uniform 0..255, one seed per global image index
     host = np.stack([np.random.default_rng(rank * B + i).integers(0, 256, (H, W, 3), dtype=np.uint8) for i in range(B)])
     x = torch.from_numpy(host).to(dev)
-    net = api.EightLayersNet(W, H, device=dev)
+    # weights: rank 0's PARAM tables, replicated with one broadcast (no-op on one GPU)
+    params = api.load_param_weights()
+    if world > 1:
+        from simple_image_compression_network_amd.dist import broadcast_params
+        if rank != 0:
+            for pair in params:
+                for t in pair:
+                    t.m_weights[...] = 0
+        broadcast_params(params, src=0, device=cdev)
+    net = api.EightLayersNet(W, H, params=params, device=dev)
     out = torch.empty((B,) + net.descs[-1].out_shape, dtype=torch.uint8, device=dev)
     latent = torch.empty((B,) + net.descs[3].out_shape, dtype=torch.uint8, device=dev)
     net.workspace(B)

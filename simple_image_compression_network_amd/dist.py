@@ -4,8 +4,8 @@ Images are independent (conv_nonsquare_top.cpp:295-357 keeps no cross-image stat
 multi-GPU parallelism of this path is along the batch: image i belongs to rank i mod world.  There
 is NO data-path collective.  The collectives here are bookkeeping (per-image checksums / timing) and
 run over whatever backend the process group was created with: "nccl" (= RCCL over xGMI) on GPUs,
-"gloo" in the CPU tests.  Weights (1.44 MB) are loaded by every rank from the same file rather
-than broadcast.
+"gloo" in the CPU tests.  Weights (1.44 MB packed) are read by rank 0 and replicated with one
+broadcast at start-up (`broadcast_params`), so every rank provably runs the same tables.
 """
 from __future__ import annotations
 
@@ -14,7 +14,7 @@ from typing import Callable, Dict, List, Sequence
 
 import numpy as np
 
-__all__ = ["shard_indices", "checksum", "run_sharded"]
+__all__ = ["shard_indices", "checksum", "run_sharded", "broadcast_params"]
 
 
 def shard_indices(n_images: int, rank: int, world: int) -> List[int]:
@@ -27,6 +27,32 @@ def shard_indices(n_images: int, rank: int, world: int) -> List[int]:
 def checksum(arr: np.ndarray) -> int:
     """Order-sensitive 32-bit checksum of a byte tensor (adler32 of the raw bytes)."""
     return zlib.adler32(np.ascontiguousarray(arr).view(np.uint8).reshape(-1)) & 0xFFFFFFFF
+
+
+def broadcast_params(params, src: int = 0, group=None, device=None):
+    """One bookkeeping collective at start-up: the `m_weights` words of every
+    (weights, bias) table of `params` (api.load_param_weights() format) are replaced IN PLACE by rank
+    `src`'s.  Ranks other than `src` only need tables of the right geometry (e.g. zeros).  No-op without
+    an initialised process group."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return params
+    backend = dist.get_backend(group)
+    dev = device if device is not None else (
+        torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu"))
+    tables = [t for pair in params for t in pair]
+    flat = np.concatenate([t.m_weights.reshape(-1) for t in tables]).view(np.uint8)     # uint64 words as bytes
+    buf = torch.from_numpy(flat.copy()).to(dev)
+    dist.broadcast(buf, src=src, group=group)
+    words = buf.cpu().numpy().view(np.uint64)
+    pos = 0
+    for t in tables:
+        n = t.m_weights.size
+        t.m_weights[...] = words[pos:pos + n].reshape(t.m_weights.shape)
+        pos += n
+    return params
 
 
 def run_sharded(n_images: int, make_image: Callable[[int], np.ndarray],
