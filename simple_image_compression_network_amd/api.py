@@ -212,6 +212,29 @@ class EightLayersNet:
                    "sicn_eight_layers_net")
         return out, latent
 
+    def capture(self, in_, out, latent=None):
+        """The whole forward pass as ONE replayable hipGraph (the launch functions neither allocate nor
+        synchronise, sicn.h): for small images the 8 launches cost more host time than device time.
+        Returns a torch.cuda.CUDAGraph; `.replay()` recomputes `out` / `latent` from the current contents
+        of `in_` (same tensors).  Keep other frees (net objects, tensors) out of the capture window."""
+        import gc
+        import torch
+        self.forward(in_, out, latent, want_latent=latent is not None)      # warm-up: module load, workspace
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=in_.device)
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    self.forward(in_, out, latent, want_latent=latent is not None)
+        finally:
+            if gc_was:
+                gc.enable()
+        return graph
+
     def run_layers(self, first: int, last: int, in_, tap_layer: int = -1, stream=None):
         """Layers [first, last] of the chain (sicn_net_forward); returns (out, tap or None)."""
         import torch

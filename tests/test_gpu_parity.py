@@ -410,3 +410,17 @@ def test_forward_is_graph_capturable(api):
     ref_out, ref_lat = net.forward(x2)
     torch.cuda.synchronize()
     assert torch.equal(got_out, ref_out) and torch.equal(got_lat, ref_lat)
+
+
+def test_capture_helper_replays(api):
+    """EightLayersNet.capture: one hipGraph for the 768x512 reference configuration; replay on new input."""
+    net = api.EightLayersNet(768, 512)
+    x = _dev(_input("ones768")[None])
+    out = torch.empty((1, 512, 768, 3), dtype=torch.uint8, device="cuda")
+    lat = torch.empty((1, 32, 48, 192), dtype=torch.uint8, device="cuda")
+    g = net.capture(x, out, lat)
+    x.copy_(_dev(_input("rng768")[None]))
+    g.replay()
+    torch.cuda.synchronize()
+    assert _sha(out[0].cpu().numpy()) == HASHES["layers"]["rng768"][7]
+    assert _sha(lat[0].cpu().numpy()) == HASHES["layers"]["rng768"][3]
