@@ -240,9 +240,6 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
     // tiles that share halo pixels share an L2 (k_common.hpp)
     const int item = xcd_logical_index(n_tiles * n_images);
     if (item < 0) return;   // before any LDS-DMA is issued
-#ifdef SICN_EXP_PRIO   // experiment: asymmetric wave priority between the two workgroups that share a CU
-    if ((((int)blockIdx.x / N_XCD) >> 5) & 1) __builtin_amdgcn_s_setprio(SICN_EXP_PRIO);
-#endif
     const int img = item / n_tiles, tile = item - img * n_tiles;
     const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
     const int Y0 = tile_y * TILE_Y, X0 = tile_x * TX;
