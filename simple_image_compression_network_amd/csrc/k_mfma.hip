@@ -138,7 +138,18 @@ __device__ __forceinline__ void k_step(v16i (&acc)[2][NTJ], Frags<NTJ> &cur, Fra
         __builtin_amdgcn_sched_barrier(0);
         mma_half<NTJ, 1>(acc, cur);
     } else {
-        load_frags<NTJ>(cur, cur_sub_patch, cur_wt, wrow, p_lane, kh, cur_oy, cur_ox);
+        // the per-lane address parts pass through a volatile asm that follows the previous step's barrier in
+        // program order: the fragment reads cannot be scheduled above that barrier (hipcc otherwise hoists
+        // them, and tile s is only published by the barrier of step s-1)
+        int pl = p_lane;
+        uint32_t wr[NTJ];
+        asm volatile("" : "+v"(pl));
+#pragma unroll
+        for (int j = 0; j < NTJ; j++) {
+            wr[j] = wrow[j];
+            asm volatile("" : "+v"(wr[j]));
+        }
+        load_frags<NTJ>(cur, cur_sub_patch, cur_wt, wr, pl, kh, cur_oy, cur_ox);
 #pragma unroll
         for (int j = 0; j < NTJ; j++) {
             acc[0][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(cur.wf[j], cur.pf[0], acc[0][j], 0, 0, 0);

@@ -87,6 +87,11 @@ __device__ __forceinline__ void pass16(v4i (&acc)[Geo<TX>::NC][NT16], const uint
 {
     constexpr int NC = Geo<TX>::NC, XT = Geo<TX>::XT;
     v4i pf[NC], wf[NT16];
+    // The fragment addresses pass through a volatile asm that follows the previous pass's barrier in
+    // program order, so the reads below cannot be scheduled above that barrier.  (hipcc did hoist them:
+    // the LDS reads of pass k+1 were issued before the barrier of pass k, which is only safe while the
+    // tiles land a whole pass early.)
+    asm volatile("" : "+v"(pix_off), "+v"(wt_off));
 #pragma unroll
     for (int c = 0; c < NC; c++) pf[c] = *(const v4i *)(patch + pix_off + ((c / XT) * Geo<TX>::PX + (c % XT) * 16) * 32);
 #pragma unroll
