@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep: every kernel family on random image sizes / batch sizes / strip cuts / tile widths against
+the numpy closed form (oracle/sicn_ref.py), bit for bit.  usage: fuzz_parity.py [--cases N] [--seed S]"""
+import argparse
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from oracle import sicn_ref  # noqa: E402  (checker)
+from simple_image_compression_network_amd import api  # noqa: E402
+from simple_image_compression_network_amd.config import LayerDesc  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=200)
+ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--chains", type=int, default=0, help="additionally: whole 8-layer chains (internal layouts) on random sizes")
+args = ap.parse_args()
+rng = np.random.default_rng(args.seed)
+
+FAMILIES = [  # (cin, cout, simd, pe, transposed)
+    (3, 128, 3, 8, 0), (128, 128, 8, 16, 0), (128, 192, 8, 24, 0), (192, 128, 12, 16, 1), (128, 128, 8, 16, 1), (128, 3, 8, 3, 1)]
+bad = 0
+for case in range(args.cases):
+    cin, cout, simd, pe, tr = FAMILIES[rng.integers(len(FAMILIES))]
+    big = rng.random() < 0.25
+    w = int(rng.integers(1, 200 if big else 70))
+    h = int(rng.integers(1, 120 if big else 40))
+    if cin == 3:
+        w, h = w * 2 + int(rng.integers(2)), h * 2 + int(rng.integers(2))
+    n = int(rng.integers(1, 4))
+    ow, oh = (2 * w, 2 * h) if tr else ((w + 1) // 2, (h + 1) // 2)
+    d = LayerDesc(IFM_CH=cin, IFM_ROW=w, IFM_COL=h, OFM_CH=cout, OFM_ROW=ow, OFM_COL=oh, SIMD=simd, PE=pe,
+                  W_TILES=(cout // pe) * (25 * cin // simd), transposed=tr)
+    d.validate()
+    env = {}
+    if rng.random() < 0.5:
+        env["SICN_STRIP_CHUNKS"] = str(int(rng.integers(1, 9)))
+    if rng.random() < 0.5:
+        env["SICN_TILE_X"] = str(rng.choice([16, 32]))
+    for k in ("SICN_STRIP_CHUNKS", "SICN_TILE_X"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    W = rng.integers(-8, 8, (cout, 5, 5, cin)).astype(np.int8)
+    b = rng.integers(-128, 128, cout).astype(np.int8)
+    words = sicn_ref.pack_finn_tiles(W, simd, pe)
+    x = rng.integers(0, 256 if cin == 3 else 128, (n,) + d.in_shape, dtype=np.uint8)
+    if cin != 3 and rng.random() < 0.3:
+        x.reshape(-1)[::5] |= 0x80
+    fpw = api.FixedPointWeights(simd, 4, pe, d.W_TILES, words)
+    fn = api.deconv522 if tr else api.conv2d
+    got = fn(d, fpw, b, torch.from_numpy(x).cuda(), None, n)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    ref_fn = sicn_ref.deconv522_ref if tr else sicn_ref.conv2d_ref
+    ok = all(np.array_equal(got[i], ref_fn(x[i], W, b)) for i in range(n))
+    if not ok:
+        bad += 1
+        print(f"MISMATCH case {case}: cin={cin} cout={cout} tr={tr} w={w} h={h} n={n} env={env}", flush=True)
+    elif case % 25 == 0:
+        print(f"case {case}: ok (cin={cin} cout={cout} tr={tr} {w}x{h} n={n} {env})", flush=True)
+print(f"{args.cases - bad}/{args.cases} cases bit-exact")
+
+# whole chains: random image sizes, random nibble weights, latent + reconstruction against the closed form
+from simple_image_compression_network_amd.config import eight_layer_descs  # noqa: E402
+cbad = 0
+for case in range(args.chains):
+    for k in ("SICN_STRIP_CHUNKS", "SICN_TILE_X"):
+        os.environ.pop(k, None)
+    if rng.random() < 0.5:
+        os.environ["SICN_TILE_X"] = str(rng.choice([16, 32]))
+    if rng.random() < 0.5:
+        os.environ["SICN_STRIP_CHUNKS"] = str(int(rng.integers(1, 6)))
+    w, h, n = int(rng.integers(1, 26)) * 16, int(rng.integers(1, 20)) * 16, int(rng.integers(1, 3))
+    descs = eight_layer_descs(w, h)
+    params_np, params = [], []
+    for d in descs:
+        Wt = rng.integers(-8, 8, (d.OFM_CH, 5, 5, d.IFM_CH)).astype(np.int8)
+        bt = rng.integers(-128, 128, d.OFM_CH).astype(np.int8)
+        params_np.append((Wt, bt, d.transposed))
+        params.append((api.FixedPointWeights(d.SIMD, 4, d.PE, d.W_TILES, sicn_ref.pack_finn_tiles(Wt, d.SIMD, d.PE)),
+                       api.FixedPointWeights(1, 8, 1, d.OFM_CH, bt.view(np.uint8).astype(np.uint64))))
+    net = api.EightLayersNet(w, h, params=params)
+    x = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    out, lat = net.forward(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    out, lat = out.cpu().numpy(), lat.cpu().numpy()
+    ok = True
+    for i in range(n):
+        ref = sicn_ref.eight_layers_net_ref(x[i], params_np)
+        ok = ok and np.array_equal(out[i], ref[7]) and np.array_equal(lat[i], ref[3])
+    if not ok:
+        cbad += 1
+        print(f"CHAIN MISMATCH {case}: {w}x{h} n={n} env={dict((k, os.environ.get(k)) for k in ('SICN_TILE_X', 'SICN_STRIP_CHUNKS'))}", flush=True)
+    elif case % 5 == 0:
+        print(f"chain {case}: ok ({w}x{h} n={n})", flush=True)
+if args.chains:
+    print(f"{args.chains - cbad}/{args.chains} chains bit-exact")
+sys.exit(1 if (bad or cbad) else 0)
