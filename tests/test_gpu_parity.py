@@ -4,7 +4,10 @@ arithmetic (no float exists on the reference path)."""
 import ctypes
 import hashlib
 import json
+import subprocess
+import sys
 from dataclasses import replace
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -17,6 +20,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 HASHES = json.loads((GOLDEN / "appendix_a_hashes.json").read_text())
+ROOT = Path(__file__).resolve().parent.parent
 
 
 @pytest.fixture(scope="module")
