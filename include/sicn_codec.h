@@ -9,7 +9,7 @@
  * tests show decode(encode(x)) == x and GPU output == CPU oracle output, byte for byte.
  *
  * Container: 48-byte header (magic "SICL", version, mode, image and latent dimensions, stream
- * count, payload size, adler32 of the latent), then for mode 2 a 128 x u16 frequency table and a
+ * count, payload size, adler32 of the latent), then for modes 2 and 3 a 128 x u16 frequency table and a
  * u32 byte count per stream, then the payload.  Symbols are latent bytes, which are < 128
  * (conv_nonsquare_top.cpp:273-275 zeroes every value with the MSB set).
  *   mode 0  raw8     payload = the latent
@@ -17,6 +17,11 @@
  *   mode 2  rANS     byte-wise rANS, 12-bit static frequencies measured on this latent, independent
  *                    streams of 1024 symbols (one GPU lane per stream), stream offsets by a
  *                    wavefront-level prefix scan
+ *   mode 3  rANS-W   the wavefront form (the one to use): streams of 16384 symbols, each coded by one wave
+ *                    whose 64 lanes hold 64 interleaved rANS states sharing one stream of 16-bit words; a
+ *                    lane's word position inside a step is a wavefront-level scan (popcount of a ballot).
+ *                    Lane l owns 4 consecutive symbols of every 256-symbol block.  Same frequency table as
+ *                    mode 2; on a 4K latent the kernels are 6-7x faster (≈55 us each way), +0.8 % bytes
  *
  * All pointers are DEVICE pointers unless named *_host.  Unlike sicn.h's launch functions, these
  * calls synchronise `hip_stream` (sizes have to come back to the caller).
@@ -34,8 +39,10 @@ extern "C" {
 #define SICN_CODEC_RAW8 0
 #define SICN_CODEC_PACKED7 1
 #define SICN_CODEC_RANS 2
+#define SICN_CODEC_RANSW 3
 #define SICN_CODEC_HEADER_BYTES 48
 #define SICN_CODEC_STREAM_SYMBOLS 1024
+#define SICN_CODEC_WSTREAM_SYMBOLS 16384 /* mode 3: 64 lanes x 256 steps */
 #define SICN_EBADMSG (-74) /* checksum of the decoded latent does not match the header */
 
 typedef struct sicn_codec_info {

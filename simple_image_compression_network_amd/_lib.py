@@ -85,6 +85,13 @@ def lib() -> ctypes.CDLL:
             raise ImportError(
                 f"{LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"or `make -C {_PKG / 'csrc'}`; there is no non-HIP fallback")
+        # PyTorch ships its own copy of the HIP runtime.  Device pointers handed to this library come from
+        # torch, so both must live in ONE runtime: load torch's first and let libsicn.so bind to it (loaded
+        # the other way round, the first launch fails with a HIP runtime error).
+        try:
+            import torch  # noqa: F401
+        except ImportError:      # symbol checks etc. work without it
+            pass
         L = ctypes.CDLL(str(LIB_PATH))
         for name, (res, args) in {**ABI, **CODEC_ABI, **CONVLAYER_ABI}.items():
             fn = getattr(L, name)          # AttributeError if the ABI is incomplete

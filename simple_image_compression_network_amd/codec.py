@@ -8,8 +8,8 @@ import ctypes
 
 from . import _lib
 
-RAW8, PACKED7, RANS = 0, 1, 2
-__all__ = ["RAW8", "PACKED7", "RANS", "encode_latent", "decode_latent", "parse_header"]
+RAW8, PACKED7, RANS, RANSW = 0, 1, 2, 3
+__all__ = ["RAW8", "PACKED7", "RANS", "RANSW", "encode_latent", "decode_latent", "parse_header"]
 
 
 def _stream_ptr(stream):
@@ -18,7 +18,7 @@ def _stream_ptr(stream):
     return ctypes.c_void_p(getattr(stream, "cuda_stream", stream))
 
 
-def encode_latent(latent, image_width: int, image_height: int, mode: int = RANS, stream=None):
+def encode_latent(latent, image_width: int, image_height: int, mode: int = RANSW, stream=None):
     """latent: CUDA uint8 tensor [H/16][W/16][C] (one image).  Returns a CUDA uint8 tensor holding the container."""
     import torch
     L = _lib.lib()

@@ -2,7 +2,12 @@
 // oracle/sicn_codec_oracle.c).  New functionality: nothing in the reference corresponds to it
 // (SURVEY.md §8f rows 1-2), parity status "unpinned".
 //
-// Parallelisation: the latent is cut into independent streams of 1024 symbols; ONE LANE encodes or
+// Two rANS forms.  Mode 3 ("rANS-W") is the wavefront form: a stream of 16384 symbols is coded by ONE
+// WAVE, its 64 lanes holding 64 interleaved rANS states that share one stream of 16-bit words; in every
+// step each lane codes one symbol and the lanes that renormalise find their word by a wavefront-level
+// scan of one ballot (rank = popcount of the emitting lanes below).  Symbols are read and written 64
+// consecutive bytes at a time.  Mode 2 is the first, lane-serial form, kept for compatibility:
+// the latent is cut into independent streams of 1024 symbols; ONE LANE encodes or
 // decodes one stream (rANS is inherently serial inside a stream), so a 4K latent (6.2 M symbols)
 // is 6 075 lanes.  Stream sizes are data dependent: every lane writes its stream backwards into a
 // fixed-capacity scratch slot, a wavefront-level prefix scan (k_scan: __shfl_up inside a wave,
@@ -20,6 +25,11 @@ namespace {
 
 constexpr uint32_t SS = SICN_CODEC_STREAM_SYMBOLS;
 constexpr uint32_t CAP = 2 * SS + 16;  // scratch bytes per stream (12-bit worst case is 1.5 B/symbol + 4)
+constexpr uint32_t WSS = SICN_CODEC_WSTREAM_SYMBOLS;   // mode 3: 64 lanes x 256 steps
+constexpr uint32_t WCAP = 2 * WSS + 256;               // at most one 16-bit word per symbol + the 64 final states
+constexpr uint32_t RANSW_L = 1u << 16;
+inline uint32_t stream_symbols(int mode) { return mode == SICN_CODEC_RANSW ? WSS : SS; }
+inline uint32_t stream_cap(int mode) { return mode == SICN_CODEC_RANSW ? WCAP : CAP; }
 constexpr uint32_t RANS_L = 1u << 23;
 constexpr int PROB_BITS = 12;
 constexpr uint32_t ADLER_MOD = 65521u;
@@ -35,7 +45,7 @@ struct Workspace {  // device pointers carved out of the caller's workspace
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-size_t carve(Workspace &w, void *base, uint32_t ns, bool with_scratch)
+size_t carve(Workspace &w, void *base, uint32_t ns, size_t scratch_per_stream)
 {
     uint8_t *p = (uint8_t *)base;
     size_t off = 0;
@@ -45,36 +55,212 @@ size_t carve(Workspace &w, void *base, uint32_t ns, bool with_scratch)
     w.lens = (uint32_t *)(p + off); off += align_up(4 * (size_t)ns + 4, 64);
     w.offsets = (uint32_t *)(p + off); off += align_up(4 * (size_t)ns + 4, 64);
     w.scratch = p + off;
-    if (with_scratch) off += (size_t)ns * CAP;
+    off += (size_t)ns * scratch_per_stream;
     return off;
 }
 
 // ---- kernels ----------------------------------------------------------------------------------
-// histogram (256 bins) + the two sums adler32 is made of; one lane per stream of 1024 symbols
-__global__ __launch_bounds__(256) void k_stats(const uint8_t *__restrict__ lat, uint32_t n, uint32_t ns,
-                                               uint32_t *__restrict__ hist, unsigned long long *__restrict__ sums)
+// histogram (256 bins) + the two sums adler32 is made of; grid-stride over 16-byte groups (consecutive lanes read
+// consecutive groups); zeros — half of a ReLU latent — are counted in a register instead of hammering one LDS bin
+__global__ __launch_bounds__(256) void k_stats(const uint8_t *__restrict__ lat, uint32_t n, uint32_t *__restrict__ hist,
+                                               unsigned long long *__restrict__ sums)
 {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t st = blockIdx.x * 256 + threadIdx.x;
     unsigned long long s1 = 0, s2 = 0;
-    if (st < ns) {
-        const uint32_t begin = st * SS, cnt = min(SS, n - begin);
-        for (uint32_t i = 0; i < cnt; i++) {
-            const uint32_t d = lat[begin + i];
+    uint32_t zeros = 0;
+    const bool vec = (reinterpret_cast<uintptr_t>(lat) & 15) == 0;
+    const uint32_t groups = vec ? n / 16 : 0;
+    for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < groups; g += gridDim.x * 256) {
+        const uint4 q = reinterpret_cast<const uint4 *>(lat)[g];
+        const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t d = (w4[k >> 2] >> (8 * (k & 3))) & 255u;
+            if (d) {
+                atomicAdd(&h[d], 1u);
+                s1 += d;
+                s2 += (unsigned long long)(n - (16 * g + k)) * d;   // < 2^39 per term, far fewer than 2^25 terms per lane
+            } else
+                zeros++;
+        }
+    }
+    for (uint32_t i = 16 * groups + blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t d = lat[i];
+        if (d) {
             atomicAdd(&h[d], 1u);
             s1 += d;
-            s2 += (unsigned long long)(n - (begin + i)) * d;
-        }
-        s2 %= ADLER_MOD;
+            s2 += (unsigned long long)(n - i) * d;
+        } else
+            zeros++;
     }
+    s2 %= ADLER_MOD;
+    // one atomic per wave, not per lane: wavefront-level reduction first
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        s1 += __shfl_down(s1, d);
+        s2 += __shfl_down(s2, d);
+        zeros += __shfl_down(zeros, d);
+    }
+    if ((threadIdx.x & 63) == 0 && zeros) atomicAdd(&h[0], zeros);
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
-    if (st < ns) {
-        atomicAdd(&sums[0], s1);
-        atomicAdd(&sums[1], s2);
+    if ((threadIdx.x & 63) == 0) {
+        if (s1) atomicAdd(&sums[0], s1);
+        if (s2) atomicAdd(&sums[1], s2 % ADLER_MOD);
     }
+}
+
+// ---- rANS-W: one wave (= one 64-lane workgroup) per stream -----------------------------------------
+// Lane l codes symbols 256 q + 4 l + k (k = 0..3) in steps 4 q + k: one aligned dword of symbols per lane and
+// 256-symbol block.  The 16-bit words live in LDS while the stream is coded (their positions are data
+// dependent: rank of the lane among the renormalising lanes = popcount of a ballot) and move between LDS and
+// global memory in whole coalesced runs.
+struct RanswTab {
+    uint32_t fc[128];   // freq | cum << 16
+    float rcp[128];     // 1 / freq, rounded down a little: the quotient estimate never exceeds the true one by more than the fix-up handles
+};
+
+__device__ __forceinline__ void ransw_build(RanswTab &t, const uint16_t *freq, int lane)
+{
+    // exclusive prefix sum of 128 frequencies by one wave: two elements per lane + wavefront scan
+    const uint32_t f0 = freq[2 * lane], f1 = freq[2 * lane + 1];
+    uint32_t incl = f0 + f1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    const uint32_t c0 = incl - f0 - f1;
+    t.fc[2 * lane] = f0 | (c0 << 16);
+    t.fc[2 * lane + 1] = f1 | ((c0 + f0) << 16);
+    t.rcp[2 * lane] = f0 ? (1.0f / (float)f0) * 0.99999988f : 0.f;
+    t.rcp[2 * lane + 1] = f1 ? (1.0f / (float)f1) * 0.99999988f : 0.f;
+}
+
+__global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__ lat, uint32_t n, uint32_t ns,
+                                                     const uint16_t *__restrict__ freq_g, uint8_t *__restrict__ scratch,
+                                                     uint32_t *__restrict__ lens)
+{
+    __shared__ RanswTab tab;
+    __shared__ __attribute__((aligned(16))) uint16_t words[WCAP / 2];
+    const uint32_t st = blockIdx.x, lane = threadIdx.x;
+    ransw_build(tab, freq_g, (int)lane);
+    __syncthreads();
+    const uint32_t begin = st * WSS, cnt = min(WSS, n - begin), blocks = (cnt + 255) / 256;
+    const bool aligned = (reinterpret_cast<uintptr_t>(lat) & 3) == 0;   // begin is a multiple of 16384
+    uint32_t pos = WCAP / 2;        // word index, the same in every lane
+    uint32_t x = RANSW_L;
+    const unsigned long long below = (1ull << lane) - 1;
+    auto load4 = [&](uint32_t q) -> uint32_t {   // the lane's 4 symbols of block q (missing ones read as 0)
+        const uint32_t j = q * 256 + lane * 4;
+        if (aligned && j + 4 <= cnt) return *reinterpret_cast<const uint32_t *>(lat + begin + j);
+        uint32_t v = 0;
+        for (int k = 0; k < 4; k++)
+            if (j + k < cnt) v |= (uint32_t)lat[begin + j + k] << (8 * k);
+        return v;
+    };
+    uint32_t nxt = blocks ? load4(blocks - 1) : 0;
+    for (uint32_t q = blocks; q-- > 0;) {
+        const uint32_t sym4 = nxt;
+        if (q) nxt = load4(q - 1);   // the next block's symbols are in flight while this one is coded
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            const bool active = q * 256 + lane * 4 + k < cnt;
+            const uint32_t sy = (sym4 >> (8 * k)) & 255u;
+            const uint32_t t = tab.fc[sy];
+            const uint32_t f = active ? (t & 0xFFFFu) : 1u, c = t >> 16;
+            const bool emit = active && (unsigned long long)x >= ((unsigned long long)f << 20);
+            const unsigned long long mask = __ballot(emit);
+            pos -= (uint32_t)__popcll(mask);
+            if (emit) {
+                words[pos + (uint32_t)__popcll(mask & below)] = (uint16_t)x;   // ascending lane order inside the step
+                x >>= 16;
+            }
+            if (active) {
+                // x / f by a float estimate (never too large by more than 1, too small by at most 2) and a fix-up
+                uint32_t qq = (uint32_t)(__uint2float_rz(x) * tab.rcp[sy]);
+                uint32_t r = x - qq * f;
+                if (r >= f) { qq++; r -= f; }
+                if (r >= f) { qq++; r -= f; }
+                if (r >= f) { qq++; r -= f; }
+                x = (qq << PROB_BITS) + r + c;
+            }
+        }
+    }
+    pos -= 128;   // the 64 final states, lane 0 first (the word index may be odd: two halves)
+    words[pos + 2 * lane] = (uint16_t)x;
+    words[pos + 2 * lane + 1] = (uint16_t)(x >> 16);
+    __syncthreads();
+    // LDS -> the tail of this stream's scratch slot, coalesced
+    uint16_t *dst = (uint16_t *)(scratch + (size_t)st * WCAP);
+    for (uint32_t i = pos + lane; i < WCAP / 2; i += 64) dst[i] = words[i];
+    if (lane == 0) lens[st] = (WCAP / 2 - pos) * 2;
+}
+
+__global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__ payload, const uint8_t *__restrict__ freq_bytes,
+                                                     const uint32_t *__restrict__ offsets, uint32_t n, uint32_t ns,
+                                                     uint8_t *__restrict__ lat, uint32_t *__restrict__ err)
+{
+    __shared__ RanswTab tab;
+    __shared__ uint16_t freq[128];
+    __shared__ uint8_t slot[4096];
+    __shared__ __attribute__((aligned(16))) uint16_t words[WCAP / 2];
+    const uint32_t st = blockIdx.x, lane = threadIdx.x;
+    freq[2 * lane] = (uint16_t)(freq_bytes[4 * lane] | (freq_bytes[4 * lane + 1] << 8));
+    freq[2 * lane + 1] = (uint16_t)(freq_bytes[4 * lane + 2] | (freq_bytes[4 * lane + 3] << 8));
+    __syncthreads();
+    ransw_build(tab, freq, (int)lane);
+    __syncthreads();
+    for (int k = 0; k < 2; k++) {
+        const uint32_t t = tab.fc[2 * lane + k], f = t & 0xFFFFu, c = t >> 16;
+        for (uint32_t v = c; v < c + f && v < 4096; v++) slot[v] = (uint8_t)(2 * lane + k);
+    }
+    const uint32_t begin = st * WSS, cnt = min(WSS, n - begin), blocks = (cnt + 255) / 256;
+    const uint32_t off = offsets[st], len = offsets[st + 1] - off;
+    if (len < 256 || (len & 1) || (off & 1) || len > WCAP) {   // streams start at even container offsets
+        if (lane == 0) atomicOr(err, 1u);
+        return;
+    }
+    const uint32_t nwords = len / 2;
+    const uint16_t *src = (const uint16_t *)(payload + off);
+    for (uint32_t i = lane; i < nwords; i += 64) words[i] = src[i];
+    __syncthreads();
+    uint32_t x = words[2 * lane] | ((uint32_t)words[2 * lane + 1] << 16);
+    uint32_t wpos = 128;
+    const unsigned long long below = (1ull << lane) - 1;
+    const bool aligned = (reinterpret_cast<uintptr_t>(lat) & 3) == 0;
+    bool bad = false;
+    for (uint32_t q = 0; q < blocks; q++) {
+        uint32_t out4 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool active = q * 256 + lane * 4 + k < cnt;
+            if (active) {
+                const uint32_t v = x & 4095u, sy = slot[v], t = tab.fc[sy];
+                out4 |= sy << (8 * k);
+                x = (t & 0xFFFFu) * (x >> PROB_BITS) + v - (t >> 16);
+            }
+            const bool need = active && x < RANSW_L;
+            const unsigned long long mask = __ballot(need);
+            if (need) {
+                const uint32_t idx = wpos + (uint32_t)__popcll(mask & below);
+                if (idx < nwords)
+                    x = (x << 16) | words[idx];
+                else
+                    bad = true;
+            }
+            wpos += (uint32_t)__popcll(mask);
+        }
+        const uint32_t j = q * 256 + lane * 4;
+        if (aligned && j + 4 <= cnt)
+            *reinterpret_cast<uint32_t *>(lat + begin + j) = out4;
+        else
+            for (int k = 0; k < 4; k++)
+                if (j + k < cnt) lat[begin + j + k] = (uint8_t)(out4 >> (8 * k));
+    }
+    if (bad || x != RANSW_L || wpos != nwords) atomicOr(err, 1u);
 }
 
 __global__ __launch_bounds__(256) void k_rans_encode(const uint8_t *__restrict__ lat, uint32_t n, uint32_t ns,
@@ -166,10 +352,10 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ in, 
 
 // one workgroup per stream: scratch tail -> payload
 __global__ __launch_bounds__(256) void k_compact(const uint8_t *__restrict__ scratch, const uint32_t *__restrict__ lens,
-                                                 const uint32_t *__restrict__ offsets, uint8_t *__restrict__ payload)
+                                                 const uint32_t *__restrict__ offsets, uint8_t *__restrict__ payload, uint32_t cap)
 {
     const uint32_t st = blockIdx.x, len = lens[st];
-    const uint8_t *src = scratch + (size_t)st * CAP + (CAP - len);
+    const uint8_t *src = scratch + (size_t)st * cap + (cap - len);
     uint8_t *dst = payload + offsets[st];
     for (uint32_t i = threadIdx.x; i < len; i += 256) dst[i] = src[i];
 }
@@ -276,7 +462,8 @@ uint32_t adler_from_sums(unsigned long long s1, unsigned long long s2, uint32_t 
 
 extern "C" size_t sicn_codec_max_bytes(int mode, uint32_t n)
 {
-    const uint32_t ns = (n + SS - 1) / SS;
+    const uint32_t ns = (n + stream_symbols(mode) - 1) / stream_symbols(mode);
+    if (mode == SICN_CODEC_RANSW) return SICN_CODEC_HEADER_BYTES + 256 + 4 * (size_t)ns + 2 * (size_t)n + 256 * (size_t)ns;
     if (mode == SICN_CODEC_RAW8) return SICN_CODEC_HEADER_BYTES + (size_t)n;
     if (mode == SICN_CODEC_PACKED7) return SICN_CODEC_HEADER_BYTES + ((size_t)n + 7) / 8 * 7;
     if (mode == SICN_CODEC_RANS) return SICN_CODEC_HEADER_BYTES + 256 + 4 * (size_t)ns + 2 * (size_t)n + 8 * (size_t)ns;
@@ -286,8 +473,8 @@ extern "C" size_t sicn_codec_max_bytes(int mode, uint32_t n)
 extern "C" size_t sicn_codec_workspace_bytes(int mode, uint32_t n)
 {
     Workspace w;
-    const uint32_t ns = (n + SS - 1) / SS;
-    return carve(w, nullptr, ns, mode == SICN_CODEC_RANS) + 64;
+    const uint32_t ns = (n + stream_symbols(mode) - 1) / stream_symbols(mode);
+    return carve(w, nullptr, ns, mode >= SICN_CODEC_RANS ? stream_cap(mode) : 0) + 64;
 }
 
 extern "C" int sicn_codec_parse_header(const uint8_t *h, size_t bytes, sicn_codec_info *info)
@@ -304,9 +491,10 @@ extern "C" int sicn_codec_parse_header(const uint8_t *h, size_t bytes, sicn_code
     info->n_streams = get32(h + 32);
     info->payload_bytes = get32(h + 40);
     info->adler32 = get32(h + 44);
-    if (info->mode > 2 || get32(h + 36) != SS) return SICN_EINVAL;
+    if (info->mode > 3 || get32(h + 36) != stream_symbols((int)info->mode)) return SICN_EINVAL;
     if ((unsigned long long)info->lat_w * info->lat_h * info->lat_c != info->n_symbols) return SICN_EINVAL;
-    if (info->n_streams != (info->n_symbols + SS - 1) / SS) return SICN_EINVAL;
+    const uint32_t ss = stream_symbols((int)info->mode);
+    if (info->n_streams != (info->n_symbols + ss - 1) / ss) return SICN_EINVAL;
     return SICN_OK;
 }
 
@@ -314,19 +502,19 @@ extern "C" int sicn_codec_encode(int mode, const uint8_t *latent, uint32_t lat_w
                                  uint32_t img_w, uint32_t img_h, uint8_t *out, size_t out_capacity, size_t *out_bytes,
                                  void *workspace, size_t workspace_bytes, void *hip_stream)
 {
-    if (!out || !out_bytes || mode < 0 || mode > 2) return SICN_EINVAL;
+    if (!out || !out_bytes || mode < 0 || mode > 3) return SICN_EINVAL;
     const unsigned long long n64 = (unsigned long long)lat_w * lat_h * lat_c;
     if (n64 > 0x7fffffffull || (n64 && !latent)) return SICN_EINVAL;
-    const uint32_t n = (uint32_t)n64, ns = (n + SS - 1) / SS;
+    const uint32_t n = (uint32_t)n64, ss = stream_symbols(mode), ns = (n + ss - 1) / ss;
     if (out_capacity < sicn_codec_max_bytes(mode, n)) return SICN_ENOSPC;
     if (!workspace || workspace_bytes < sicn_codec_workspace_bytes(mode, n)) return SICN_ENOSPC;
     hipStream_t stream = (hipStream_t)hip_stream;
     Workspace w;
-    carve(w, workspace, ns, mode == SICN_CODEC_RANS);
+    carve(w, workspace, ns, mode >= SICN_CODEC_RANS ? stream_cap(mode) : 0);
 
     // statistics (also the checksum and the symbol-range check) -------------------------------
     HIP_TRY(hipMemsetAsync(w.hist, 0, 1024 + 64, stream));
-    if (ns) hipLaunchKernelGGL(k_stats, dim3((ns + 255) / 256), dim3(256), 0, stream, latent, n, ns, w.hist, w.sums);
+    if (n) hipLaunchKernelGGL(k_stats, dim3(min((n / 16 + 255u) / 256u + 1u, 128u)), dim3(256), 0, stream, latent, n, w.hist, w.sums);
     uint32_t hist[256];
     unsigned long long sums[2];
     HIP_TRY(hipMemcpyAsync(hist, w.hist, sizeof hist, hipMemcpyDeviceToHost, stream));
@@ -347,7 +535,7 @@ extern "C" int sicn_codec_encode(int mode, const uint8_t *latent, uint32_t lat_w
     put32(head + 24, lat_c);
     put32(head + 28, n);
     put32(head + 32, ns);
-    put32(head + 36, SS);
+    put32(head + 36, ss);
     put32(head + 44, adler_from_sums(sums[0], sums[1], n));
 
     size_t total;
@@ -373,9 +561,12 @@ extern "C" int sicn_codec_encode(int mode, const uint8_t *latent, uint32_t lat_w
         HIP_TRY(hipMemcpyAsync(w.freq, freq, sizeof freq, hipMemcpyHostToDevice, stream));
         uint8_t *table = out + SICN_CODEC_HEADER_BYTES + 256;
         uint8_t *payload = table + 4 * (size_t)ns;
-        if (ns) hipLaunchKernelGGL(k_rans_encode, dim3((ns + 255) / 256), dim3(256), 0, stream, latent, n, ns, w.freq, w.scratch, w.lens);
+        if (ns && mode == SICN_CODEC_RANSW)
+            hipLaunchKernelGGL(k_ransw_encode, dim3(ns), dim3(64), 0, stream, latent, n, ns, w.freq, w.scratch, w.lens);
+        else if (ns)
+            hipLaunchKernelGGL(k_rans_encode, dim3((ns + 255) / 256), dim3(256), 0, stream, latent, n, ns, w.freq, w.scratch, w.lens);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, w.lens, (const uint8_t *)nullptr, ns, w.offsets, table, out + 40);
-        if (ns) hipLaunchKernelGGL(k_compact, dim3(ns), dim3(256), 0, stream, w.scratch, w.lens, w.offsets, payload);
+        if (ns) hipLaunchKernelGGL(k_compact, dim3(ns), dim3(256), 0, stream, w.scratch, w.lens, w.offsets, payload, stream_cap(mode));
         uint32_t payload_bytes = 0;
         HIP_TRY(hipMemcpyAsync(&payload_bytes, w.offsets + ns, 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -404,7 +595,7 @@ extern "C" int sicn_codec_decode(const uint8_t *container, size_t bytes, uint8_t
     if (n && (!latent || latent_capacity < n)) return SICN_ENOSPC;
     if (!workspace || workspace_bytes < sicn_codec_workspace_bytes((int)info.mode, n)) return SICN_ENOSPC;
     Workspace w;
-    carve(w, workspace, ns, false);
+    carve(w, workspace, ns, 0);
     HIP_TRY(hipMemsetAsync(w.hist, 0, 1024 + 64, stream));
     uint32_t *err = w.hist + 255;  // bins >= 128 stay zero for a valid latent: reuse the last one as error flag
 
@@ -435,7 +626,10 @@ extern "C" int sicn_codec_decode(const uint8_t *container, size_t bytes, uint8_t
         HIP_TRY(hipMemcpyAsync(&total, w.offsets + ns, 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (total != info.payload_bytes) return SICN_EINVAL;
-        if (ns) hipLaunchKernelGGL(k_rans_decode, dim3((ns + 255) / 256), dim3(256), 0, stream, payload, freq_bytes, w.offsets, n, ns, latent, err);
+        if (ns && info.mode == SICN_CODEC_RANSW)
+            hipLaunchKernelGGL(k_ransw_decode, dim3(ns), dim3(64), 0, stream, payload, freq_bytes, w.offsets, n, ns, latent, err);
+        else if (ns)
+            hipLaunchKernelGGL(k_rans_decode, dim3((ns + 255) / 256), dim3(256), 0, stream, payload, freq_bytes, w.offsets, n, ns, latent, err);
     }
     // checksum of what was decoded
     uint32_t flag = 0;
@@ -443,7 +637,7 @@ extern "C" int sicn_codec_decode(const uint8_t *container, size_t bytes, uint8_t
     HIP_TRY(hipStreamSynchronize(stream));
     if (flag) return SICN_EINVAL;
     HIP_TRY(hipMemsetAsync(w.hist, 0, 1024 + 64, stream));
-    if (ns) hipLaunchKernelGGL(k_stats, dim3((ns + 255) / 256), dim3(256), 0, stream, latent, n, ns, w.hist, w.sums);
+    if (n) hipLaunchKernelGGL(k_stats, dim3(min((n / 16 + 255u) / 256u + 1u, 128u)), dim3(256), 0, stream, latent, n, w.hist, w.sums);
     unsigned long long sums[2];
     HIP_TRY(hipMemcpyAsync(sums, w.sums, sizeof sums, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));

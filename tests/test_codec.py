@@ -23,11 +23,12 @@ def _mock_latent(rng, shape, zero_frac=0.5):
     return lat
 
 
-SHAPES = [(16, 16, 192), (1, 1, 192), (3, 5, 7), (0, 4, 4), (2, 2, 1), (8, 3, 192), (64, 1, 16)]
+SHAPES = [(16, 16, 192), (1, 1, 192), (3, 5, 7), (0, 4, 4), (2, 2, 1), (8, 3, 192), (64, 1, 16), (1, 1, 64), (1, 1, 65),
+          (9, 10, 192)]   # the last one: 17280 symbols = one full 16384-symbol wave stream + a short one
 
 
 @pytest.mark.parametrize("shape", SHAPES)
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_oracle_round_trip(shape, mode):
     rng = np.random.default_rng(sum(shape) * 3 + mode)
     lat = _mock_latent(rng, shape)
@@ -56,12 +57,29 @@ def test_extreme_distributions_round_trip():
                 np.arange(128, dtype=np.uint8).reshape(1, 1, 128),
                 np.concatenate([np.zeros(5000, np.uint8), np.array([77], np.uint8)]).reshape(1, 1, -1),   # freq 1 symbol
                 rng.integers(0, 128, (5, 41, 6), dtype=np.uint8)):
-        for mode in (0, 1, 2):
+        for mode in (0, 1, 2, 3):
             out, _ = c_oracle.codec_decode(c_oracle.codec_encode(lat, (0, 0), mode))
             assert np.array_equal(out, lat)
     # a constant latent costs almost nothing under rANS: 4 state bytes + <= 1 byte per 1024-symbol stream
     blob = c_oracle.codec_encode(np.zeros((16, 16, 192), np.uint8), (256, 256), 2)
     assert len(blob) < 48 + 256 + 48 * 4 + 48 * 8
+
+
+def test_wave_form_layout():
+    """Mode 3: stream_symbols 16384, per stream 64 little-endian u32 states then 16-bit words; one state per lane
+    even for a stream shorter than 64 symbols, and the idle lanes keep the initial state 2^16."""
+    lat = _mock_latent(np.random.default_rng(8), (1, 1, 40))
+    blob = c_oracle.codec_encode(lat, (16, 16), 3)
+    magic, ver, mode, iw, ih, lw, lh, lc, n, ns, ss, payload, adler = struct.unpack("<4sHHIIIIIIIIII", blob[:48])
+    assert (mode, n, ns, ss) == (3, 40, 1, 16384)
+    (len0,) = struct.unpack("<I", blob[304:308])
+    assert payload == len0 == len(blob) - 308 and len0 % 2 == 0 and len0 >= 256
+    states = np.frombuffer(blob[308:308 + 256], "<u4")   # 40 symbols = 4 per lane on lanes 0..9
+    assert np.all(states[10:] == 1 << 16) and np.all(states[:10] >= 1 << 16)
+    # the wave form costs at most the 252 extra flush bytes per stream plus word granularity
+    big = _mock_latent(np.random.default_rng(9), (32, 32, 192))
+    a, b = len(c_oracle.codec_encode(big, (0, 0), 2)), len(c_oracle.codec_encode(big, (0, 0), 3))
+    assert b < a * 1.02
 
 
 def test_rejects_symbols_over_127_and_corruption():
@@ -70,10 +88,11 @@ def test_rejects_symbols_over_127_and_corruption():
     bad[0, 0, 0] = 200
     with pytest.raises(RuntimeError):
         c_oracle.codec_encode(bad, (0, 0), 2)
-    blob = bytearray(c_oracle.codec_encode(lat, (64, 64), 2))
-    blob[-5] ^= 0x40                                       # flip a payload bit
-    with pytest.raises(RuntimeError):
-        c_oracle.codec_decode(bytes(blob))
+    for mode in (2, 3):
+        blob = bytearray(c_oracle.codec_encode(lat, (64, 64), mode))
+        blob[-5] ^= 0x40                                   # flip a payload bit
+        with pytest.raises(RuntimeError):
+            c_oracle.codec_decode(bytes(blob))
     with pytest.raises(RuntimeError):
         c_oracle.codec_decode(bytes(blob[:40]))            # truncated header
 
@@ -94,7 +113,7 @@ def test_codec_abi_symbols_exported():
     text = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "sicn_codec.h").read_text(), flags=re.S)
     syms = sorted(set(re.findall(r"\b(sicn_codec_[a-z0-9_]+)\s*\(", text)))
     from simple_image_compression_network_amd import _lib
-    L = ctypes.CDLL(str(_lib.LIB_PATH))
+    L = _lib.lib()        # (loads the HIP runtime PyTorch ships first, then libsicn.so)
     assert set(syms) == set(_lib.CODEC_ABI) and all(hasattr(L, s) for s in syms)
     info = _lib.CodecInfo()
     blob = c_oracle.codec_encode(_mock_latent(np.random.default_rng(5), (2, 3, 4)), (48, 32), 1)
@@ -116,7 +135,7 @@ def test_gpu_container_equals_oracle_and_round_trips(shape):
     rng = np.random.default_rng(sum(shape))
     lat = _mock_latent(rng, shape)
     dev = torch.from_numpy(lat).cuda()
-    for mode in (codec.RAW8, codec.PACKED7, codec.RANS):
+    for mode in (codec.RAW8, codec.PACKED7, codec.RANS, codec.RANSW):
         blob = codec.encode_latent(dev, shape[1] * 16, shape[0] * 16, mode)
         host = blob.cpu().numpy().tobytes()
         assert host == c_oracle.codec_encode(lat, (shape[1] * 16, shape[0] * 16), mode), f"mode {mode}"
@@ -134,9 +153,10 @@ def test_gpu_codec_on_real_latent_and_errors():
     x = np.random.default_rng(0).integers(0, 256, (1, 512, 768, 3), dtype=np.uint8)
     net = api.EightLayersNet(768, 512)
     _, latent = net.forward(torch.from_numpy(x).cuda())
-    blob = codec.encode_latent(latent[0], 768, 512, codec.RANS)
-    back, info = codec.decode_latent(blob)
-    assert torch.equal(back, latent[0])
+    for mode in (codec.RANS, codec.RANSW):
+        blob = codec.encode_latent(latent[0], 768, 512, mode)
+        back, info = codec.decode_latent(blob)
+        assert torch.equal(back, latent[0]) and info.mode == mode
     assert (info.lat_w, info.lat_h, info.lat_c, info.image_width) == (48, 32, 192, 768)
     assert blob.numel() < latent[0].numel()                 # order-0 entropy of this latent is ~4.5 bit/symbol
     # decoding the decoded latent's reconstruction is the same as without the codec in between

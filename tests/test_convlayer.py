@@ -71,7 +71,7 @@ def test_convlayer_abi_symbols_and_validation():
     from simple_image_compression_network_amd import _lib
     text = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "sicn_convlayer.h").read_text(), flags=re.S)
     syms = sorted(set(re.findall(r"\b(sicn_conv[a-z0-9_]*)\s*\(", text)))
-    L = ctypes.CDLL(str(_lib.LIB_PATH))
+    L = _lib.lib()        # (loads the HIP runtime PyTorch ships first, then libsicn.so)
     assert set(syms) == set(_lib.CONVLAYER_ABI) and all(hasattr(L, s) for s in syms)
     from simple_image_compression_network_amd.convlayer import ConvLayerDesc, PassThroughActivation
     good = ConvLayerDesc(K=3, IFM_CH=4, IFM_DIM=9, OFM_CH=6, SIMD=2, PE=3).to_c(PassThroughActivation(16, True))

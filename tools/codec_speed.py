@@ -17,7 +17,7 @@ _, lat = net.forward(x)
 torch.cuda.synchronize()
 lat0 = lat[0].contiguous()
 n = lat0.numel()
-for mode, name in ((codec.RAW8, "raw8"), (codec.PACKED7, "packed7"), (codec.RANS, "rANS")):
+for mode, name in ((codec.RAW8, "raw8"), (codec.PACKED7, "packed7"), (codec.RANS, "rANS"), (codec.RANSW, "rANS-W")):
     c = codec.encode_latent(lat0, W, H, mode)
     back, _ = codec.decode_latent(c)
     torch.cuda.synchronize()
