@@ -18,7 +18,8 @@
  * In the reference this surface is only instantiated in a commented-out line
  * (conv_nonsquare_top.cpp:223), so there are no reference outputs to pin it with: parity status
  * UNPINNED (restated from the cited source; GPU == CPU restatement in the tests).  It is served by
- * a shape-agnostic HIP kernel — a functional surface, not a tuned hot path (the hot path is sicn.h).
+ * an int8 MFMA implicit-GEMM kernel when IFM_CH is a multiple of 16 and by a shape-agnostic direct
+ * kernel otherwise — a functional surface, not a tuned hot path (the hot path is sicn.h).
  *
  * Data model: input [reps][IFM_DIM][IFM_DIM][IFM_CH] with one BYTE per lane (IN_BIT <= 8, the byte
  * holds the lane value as uint8 or int8); output [reps][OFM_DIM][OFM_DIM][OFM_CH] with one

@@ -4,9 +4,18 @@
 //   acc  = wrap_TA( sum_{ky,kx,c} x[y+ky][x+kx][c] * W[o][(ky*K+kx)*C + c] )      mvau.hpp:87-179
 //   out  = low OUT_BIT bits of  activation(acc)                                    activations.hpp:127-190
 // Stride 1, no padding, square image (convlayer.h:116-118).  Parity unpinned (no reference outputs
-// exist for this surface, sicn_convlayer.h); functional surface, not a tuned hot path.
+// exist for this surface, sicn_convlayer.h).
+//
+// Two kernels.  k_convlayer_mfma (IFM_CH a multiple of 16): implicit GEMM on v_mfma_i32_16x16x64_i8 —
+// a wave owns 64 consecutive output positions x 64 output channels (16 accumulator tiles); a K step is
+// 64 channel bytes of ONE kernel tap, read straight from the NHWC image (16 bytes per lane, the cache
+// hierarchy serves the K*K-fold reuse), weights from a zero-padded [O/16][tap][C/64][16][64] image.
+// int8 x int8 is signed x signed: unsigned inputs are read as x - 128 (one v_xor per dword) and
+// 128 * sum_k W[o][k] is the accumulators' start value.  k_convlayer: one thread per output lane, direct
+// evaluation, for every other shape.  Neither is a tuned hot path (that is sicn.h).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -17,6 +26,8 @@ struct sicn_convlayer_params {
     sicn_convlayer_desc d;
     int8_t *d_w_okc;     // [OFM_CH][K*K*IFM_CH] sign-extended weights
     int32_t *d_thr;      // [OFM_CH][NUM_TH] thresholds in channel order, or nullptr
+    int8_t *d_w_mfma;    // [ceil(O/16)][K*K][ceil(C/64)][16 rows][64 bytes], zero padded; nullptr if C % 16 != 0
+    int32_t *d_wsum;     // [ceil(O/16)*16] sum_k W[o][k]
 };
 
 namespace {
@@ -69,6 +80,99 @@ __global__ __launch_bounds__(256) void k_convlayer(const uint8_t *__restrict__ i
         ((uint32_t *)out)[oi] = (uint32_t)r;
 }
 
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+// wave = 64 consecutive output positions (4 column tiles of 16) x 64 output channels (4 weight tiles)
+__global__ __launch_bounds__(256) void k_convlayer_mfma(const uint8_t *__restrict__ in, void *__restrict__ out,
+                                                        const int8_t *__restrict__ wm, const int32_t *__restrict__ wsum,
+                                                        const int32_t *__restrict__ thr, sicn_convlayer_desc d)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = lane & 15, g = lane >> 4;
+    const int C = d.IFM_CH, K = d.K, D = d.IFM_DIM, OD = d.OFM_DIM, O = d.OFM_CH;
+    const int npos = OD * OD, nchunk = (C + 63) / 64, KK = K * K;
+    const int p0 = (blockIdx.x * 4 + wv) * 64;            // first position of this wave
+    const int j0 = blockIdx.y * 4;                        // first 16-channel weight tile
+    const int ntile = (O + 15) / 16;
+    const uint8_t *img = in + (size_t)blockIdx.z * D * D * C;
+    if (p0 >= npos) return;
+
+    // this lane's pixel (per column tile): top-left corner of its window, as a byte offset
+    uint32_t pix[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        int p = p0 + 16 * c + col;
+        p = p < npos ? p : npos - 1;                      // clamped positions are computed and not stored
+        const int y = p / OD, x = p - y * OD;
+        pix[c] = (uint32_t)((y * D + x) * C);
+    }
+    v4i_t acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        v4i_t b;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int o = (j0 + j) * 16 + 4 * g + r;       // C/D row 4g + r of tile j
+            b[r] = (d.IN_SIGNED || j0 + j >= ntile) ? 0 : 128 * wsum[o];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[c][j] = b;
+    }
+    const uint32_t flip = d.IN_SIGNED ? 0u : 0x80808080u;
+    for (int t = 0; t < KK; t++) {
+        const int ky = t / K, kx = t - ky * K;
+        const uint32_t tap = (uint32_t)((ky * D + kx) * C);
+        for (int cc = 0; cc < nchunk; cc++) {
+            const int c0 = cc * 64 + 16 * g;              // this lane's 16 channel bytes of the K step
+            const bool valid = c0 < C;                     // C % 16 == 0: a 16-byte group is all in or all out (weights 0)
+            v4i_t bf[4], af[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(img + pix[c] + tap + (valid ? c0 : 0));
+                bf[c] = v4i_t{(int)(q.x ^ flip), (int)(q.y ^ flip), (int)(q.z ^ flip), (int)(q.w ^ flip)};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int jj = j0 + j < ntile ? j0 + j : ntile - 1;
+                af[j] = *reinterpret_cast<const v4i_t *>(wm + ((((size_t)jj * KK + t) * nchunk + cc) * 16 + col) * 64 + 16 * g);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[c][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[j], bf[c], acc[c][j], 0, 0, 0);
+        }
+    }
+    // epilogue: lane holds, per (column tile c, weight tile j), channels 16(j0+j) + 4g .. +3 of position p0 + 16c + col
+    const size_t per_img = (size_t)npos * O;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int p = p0 + 16 * c + col;
+        if (p >= npos) continue;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int o = (j0 + j) * 16 + 4 * g + r;
+                if (o >= O) continue;
+                const long long a = wrap_acc((long long)acc[c][j][r], d.ACC_BIT, d.ACC_SIGNED);
+                long long res = a;
+                if (d.activation == SICN_ACT_THRESHOLDS) {
+                    res = d.ACT_VAL;
+                    const int32_t *tt = thr + (size_t)o * d.NUM_TH;
+                    for (int i = 0; i < d.NUM_TH; i++) res += (wrap_acc((long long)tt[i], d.ACC_BIT, d.ACC_SIGNED) < a) ? 1 : 0;
+                }
+                const size_t oi = (size_t)blockIdx.z * per_img + (size_t)p * O + o;
+                if (d.OUT_BIT == 8)
+                    ((uint8_t *)out)[oi] = (uint8_t)res;
+                else if (d.OUT_BIT == 16)
+                    ((uint16_t *)out)[oi] = (uint16_t)res;
+                else
+                    ((uint32_t *)out)[oi] = (uint32_t)res;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int sicn_convlayer_validate(const sicn_convlayer_desc *d)
@@ -96,6 +200,8 @@ extern "C" void sicn_convlayer_params_free(sicn_convlayer_params *p)
     if (!p) return;
     if (p->d_w_okc) (void)hipFree(p->d_w_okc);
     if (p->d_thr) (void)hipFree(p->d_thr);
+    if (p->d_w_mfma) (void)hipFree(p->d_w_mfma);
+    if (p->d_wsum) (void)hipFree(p->d_wsum);
     delete p;
 }
 
@@ -141,8 +247,33 @@ extern "C" int sicn_convlayer_params_create(const sicn_convlayer_desc *d, const 
     p->d = *d;
     p->d_w_okc = nullptr;
     p->d_thr = nullptr;
+    p->d_w_mfma = nullptr;
+    p->d_wsum = nullptr;
     bool ok = hipMalloc((void **)&p->d_w_okc, w.size()) == hipSuccess &&
               hipMemcpy(p->d_w_okc, w.data(), w.size(), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && d->IFM_CH % 16 == 0) {   // the MFMA image: [O/16][tap][C/64][16 rows][64 bytes], zero padded
+        const int KK = d->K * d->K, nchunk = (d->IFM_CH + 63) / 64, ntile = (d->OFM_CH + 15) / 16;
+        std::vector<int8_t> wm;
+        std::vector<int32_t> ws;
+        try {
+            wm.assign((size_t)ntile * KK * nchunk * 16 * 64, 0);
+            ws.assign((size_t)ntile * 16, 0);
+        } catch (const std::bad_alloc &) {
+            sicn_convlayer_params_free(p);
+            return SICN_ENOMEM;
+        }
+        for (int o = 0; o < d->OFM_CH; o++)
+            for (int t = 0; t < KK; t++)
+                for (int c = 0; c < d->IFM_CH; c++) {
+                    const int8_t v = w[(size_t)o * kk + t * d->IFM_CH + c];
+                    wm[((((size_t)(o / 16) * KK + t) * nchunk + c / 64) * 16 + o % 16) * 64 + c % 64] = v;
+                    ws[o] += v;
+                }
+        ok = hipMalloc((void **)&p->d_w_mfma, wm.size()) == hipSuccess &&
+             hipMemcpy(p->d_w_mfma, wm.data(), wm.size(), hipMemcpyHostToDevice) == hipSuccess &&
+             hipMalloc((void **)&p->d_wsum, ws.size() * 4) == hipSuccess &&
+             hipMemcpy(p->d_wsum, ws.data(), ws.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (ok && thresholds)
         ok = hipMalloc((void **)&p->d_thr, t.size() * 4) == hipSuccess &&
              hipMemcpy(p->d_thr, t.data(), t.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
@@ -168,6 +299,14 @@ extern "C" int sicn_conv_layer_batch(const sicn_convlayer_desc *d, const sicn_co
     const size_t per_img = (size_t)d->OFM_DIM * d->OFM_DIM * d->OFM_CH;
     const size_t blocks = (per_img + 255) / 256;
     if (blocks > 0x7fffffffu) return SICN_EINVAL;
+    const char *force = getenv("SICN_CONVLAYER_GENERIC");   // tests: compare the two kernels
+    if (p->d_w_mfma && (size_t)d->IFM_DIM * d->IFM_DIM * d->IFM_CH < 0x7fffffffu && !(force && force[0] == '1')) {
+        const unsigned npos = (unsigned)(d->OFM_DIM * d->OFM_DIM);
+        dim3 grid((npos + 255) / 256, (unsigned)((d->OFM_CH + 63) / 64), (unsigned)reps);
+        hipLaunchKernelGGL(k_convlayer_mfma, grid, dim3(256), 0, (hipStream_t)hip_stream, in, out, p->d_w_mfma, p->d_wsum,
+                           p->d_thr, *d);
+        return hipGetLastError() == hipSuccess ? SICN_OK : SICN_ENODEV;
+    }
     hipLaunchKernelGGL(k_convlayer, dim3((unsigned)blocks, (unsigned)reps), dim3(256), 0, (hipStream_t)hip_stream, in, out,
                        p->d_w_okc, p->d_thr, *d);
     return hipGetLastError() == hipSuccess ? SICN_OK : SICN_ENODEV;

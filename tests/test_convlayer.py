@@ -23,6 +23,12 @@ CASES = [
     (3, 4, 9, 6, 4, 2, 4, 0, 16, 1, 8, 3, 0),        # 3 thresholds -> 2-bit activations
     (2, 8, 7, 12, 8, 6, 3, 1, 10, 1, 8, 15, -8),     # 15 thresholds, ActVal -8 (signed 4-bit result in a byte lane)
     (7, 2, 10, 2, 2, 1, 5, 0, 24, 0, 32, 1, 0),      # one threshold (sign), unsigned accumulator compare
+    # IFM_CH % 16 == 0: served by the MFMA kernel on the GPU (the others by the direct one)
+    (3, 16, 9, 6, 8, 3, 4, 0, 16, 1, 16, 0, 0),      # one 16-byte channel group, O not a multiple of 16, unsigned inputs
+    (1, 64, 6, 40, 8, 8, 8, 1, 32, 1, 32, 0, 0),     # 1x1, signed inputs, 8-bit weights, 3 channel tiles (one partial)
+    (3, 48, 10, 20, 8, 4, 4, 0, 8, 0, 8, 0, 0),      # C = 48: a partial 64-byte K step; the net's ap_uint<8> accumulator
+    (5, 32, 12, 70, 8, 7, 3, 0, 14, 1, 8, 7, -4),    # 7 thresholds, 70 channels: two grid rows of channel tiles
+    (2, 128, 20, 16, 8, 8, 2, 1, 12, 1, 16, 0, 0),   # two full K steps per tap, 361 positions: partial position tile
 ]
 
 
@@ -101,3 +107,26 @@ def test_gpu_conv_layer_batch_matches_oracle(case):
     assert np.array_equal(got[0], ref.astype(np.int64))
     ref1 = c_oracle.convlayer_dataflow(d, words, thr, x[::-1].copy(), use_fsm=False)
     assert np.array_equal(got[1], ref1.astype(np.int64))
+
+
+@pytest.mark.gpu
+def test_gpu_mfma_and_direct_kernels_agree(monkeypatch):
+    """The same layer through k_convlayer_mfma (default when IFM_CH % 16 == 0) and through the direct kernel
+    (SICN_CONVLAYER_GENERIC=1), on a shape large enough for several workgroups."""
+    import torch
+    from simple_image_compression_network_amd.api import FixedPointWeights
+    from simple_image_compression_network_amd.convlayer import ConvLayer_Batch, ConvLayerDesc, PassThroughActivation
+    rng = np.random.default_rng(77)
+    K, C, D, O = 3, 64, 40, 96
+    w = rng.integers(-8, 8, (O, K * K * C)).astype(np.int8)
+    words = sicn_ref.pack_finn_tiles_generic(w, 8, 8, 4)
+    desc = ConvLayerDesc(K=K, IFM_CH=C, IFM_DIM=D, OFM_CH=O, SIMD=8, PE=8, W_BIT=4, IN_SIGNED=False, OUT_BIT=32)
+    act = PassThroughActivation(24, True)
+    x = torch.from_numpy(rng.integers(0, 256, (3, D, D, C), dtype=np.uint8)).cuda()
+    fpw = FixedPointWeights(8, 4, 8, desc.W_TILES, words)
+    a = ConvLayer_Batch(desc, x, None, fpw, act, 3).clone()
+    monkeypatch.setenv("SICN_CONVLAYER_GENERIC", "1")
+    b = ConvLayer_Batch(desc, x, None, fpw, act, 3)
+    assert torch.equal(a, b)
+    ref = sicn_ref.conv_layer_batch_ref(x[1].cpu().numpy(), w, K, False, 24, True, 32)
+    assert np.array_equal(a[1].cpu().numpy().astype(np.int64) & 0xFFFFFFFF, ref.astype(np.int64))
