@@ -67,6 +67,18 @@ int sicn_codec_parse_header(const uint8_t *header_host, size_t bytes, sicn_codec
 int sicn_codec_decode(const uint8_t *container, size_t bytes, uint8_t *latent, size_t latent_capacity,
                       sicn_codec_info *info_or_null, void *workspace, size_t workspace_bytes, void *hip_stream);
 
+/* Batches (mode SICN_CODEC_RANSW only): n_images latents of one shape, `latents` = [n][lat_h][lat_w][lat_c], container i
+ * at `out + i * slot_bytes` (slot_bytes >= sicn_codec_max_bytes, even), its size in out_bytes_host[i].  Byte-identical
+ * to n single calls, with two host synchronisations per batch instead of three per image. */
+size_t sicn_codec_batch_workspace_bytes(int mode, uint32_t n_symbols, uint32_t n_images);
+int sicn_codec_encode_batch(int mode, const uint8_t *latents, uint32_t n_images, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c,
+                            uint32_t image_width, uint32_t image_height, uint8_t *out, size_t slot_bytes,
+                            size_t *out_bytes_host, void *workspace, size_t workspace_bytes, void *hip_stream);
+/* containers[i] at `containers + i * slot_bytes` with bytes_host[i] valid bytes -> latents + i * latent_stride. */
+int sicn_codec_decode_batch(const uint8_t *containers, size_t slot_bytes, const size_t *bytes_host, uint32_t n_images,
+                            uint8_t *latents, size_t latent_stride, sicn_codec_info *infos_or_null, void *workspace,
+                            size_t workspace_bytes, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,9 @@ CODEC_ABI = {
     "sicn_codec_encode": (_i, [_i, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _sz, ctypes.POINTER(_sz), _vp, _sz, _vp]),
     "sicn_codec_parse_header": (_i, [_vp, _sz, ctypes.POINTER(CodecInfo)]),
     "sicn_codec_decode": (_i, [_vp, _sz, _vp, _sz, ctypes.POINTER(CodecInfo), _vp, _sz, _vp]),
+    "sicn_codec_batch_workspace_bytes": (_sz, [_i, _u32, _u32]),
+    "sicn_codec_encode_batch": (_i, [_i, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _sz, ctypes.POINTER(_sz), _vp, _sz, _vp]),
+    "sicn_codec_decode_batch": (_i, [_vp, _sz, ctypes.POINTER(_sz), _u32, _vp, _sz, ctypes.POINTER(CodecInfo), _vp, _sz, _vp]),
 }
 
 _lib = None

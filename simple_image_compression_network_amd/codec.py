@@ -9,7 +9,8 @@ import ctypes
 from . import _lib
 
 RAW8, PACKED7, RANS, RANSW = 0, 1, 2, 3
-__all__ = ["RAW8", "PACKED7", "RANS", "RANSW", "encode_latent", "decode_latent", "parse_header"]
+__all__ = ["RAW8", "PACKED7", "RANS", "RANSW", "encode_latent", "decode_latent", "parse_header", "encode_latents",
+           "decode_latents"]
 
 
 def _stream_ptr(stream):
@@ -55,3 +56,41 @@ def decode_latent(container, stream=None):
                                    ctypes.c_void_p(latent.data_ptr()), max(n, 1), ctypes.byref(info),
                                    ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr(stream)), "sicn_codec_decode")
     return latent, info
+
+
+def encode_latents(latents, image_width: int, image_height: int, stream=None):
+    """latents: CUDA uint8 tensor [n][H/16][W/16][C].  One rANS-W container per image, byte-identical to
+    `encode_latent(latents[i], ...)`, with two host synchronisations for the whole batch.  Returns
+    (slots, sizes): a CUDA uint8 tensor [n][slot_bytes] and the list of valid byte counts."""
+    import torch
+    L = _lib.lib()
+    if not (latents.is_cuda and latents.dtype == torch.uint8 and latents.is_contiguous() and latents.dim() == 4):
+        raise TypeError("latents must be a contiguous CUDA uint8 tensor [n][h][w][c]")
+    nimg, h, w, c = (int(v) for v in latents.shape)
+    n = h * w * c
+    slot = (int(L.sicn_codec_max_bytes(RANSW, n)) + 255) // 256 * 256
+    out = torch.empty((nimg, slot), dtype=torch.uint8, device=latents.device)
+    ws = torch.empty(max(L.sicn_codec_batch_workspace_bytes(RANSW, n, nimg), 64), dtype=torch.uint8, device=latents.device)
+    sizes = (ctypes.c_size_t * max(nimg, 1))()
+    _lib.check(L.sicn_codec_encode_batch(RANSW, ctypes.c_void_p(latents.data_ptr()), nimg, w, h, c, image_width, image_height,
+                                         ctypes.c_void_p(out.data_ptr()), slot, sizes, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                         _stream_ptr(stream)), "sicn_codec_encode_batch")
+    return out, [int(sizes[i]) for i in range(nimg)]
+
+
+def decode_latents(slots, sizes, stream=None):
+    """Inverse of `encode_latents`: (slots [n][slot_bytes], sizes) -> (latents [n][h][w][c], [CodecInfo])."""
+    import torch
+    L = _lib.lib()
+    nimg, slot = (int(v) for v in slots.shape)
+    info0 = parse_header(bytes(slots[0, :48].cpu().numpy().tobytes()))
+    n = int(info0.n_symbols)
+    latents = torch.empty((nimg, int(info0.lat_h), int(info0.lat_w), int(info0.lat_c)), dtype=torch.uint8, device=slots.device)
+    ws = torch.empty(max(L.sicn_codec_batch_workspace_bytes(RANSW, n, nimg), 64), dtype=torch.uint8, device=slots.device)
+    csz = (ctypes.c_size_t * nimg)(*sizes)
+    infos = (_lib.CodecInfo * nimg)()
+    slots = slots.contiguous()
+    _lib.check(L.sicn_codec_decode_batch(ctypes.c_void_p(slots.data_ptr()), slot, csz, nimg, ctypes.c_void_p(latents.data_ptr()),
+                                         max(n, 1), infos, ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr(stream)),
+               "sicn_codec_decode_batch")
+    return latents, list(infos)

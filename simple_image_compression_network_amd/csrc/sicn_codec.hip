@@ -62,9 +62,25 @@ size_t carve(Workspace &w, void *base, uint32_t ns, size_t scratch_per_stream)
 // ---- kernels ----------------------------------------------------------------------------------
 // histogram (256 bins) + the two sums adler32 is made of; grid-stride over 16-byte groups (consecutive lanes read
 // consecutive groups); zeros — half of a ReLU latent — are counted in a register instead of hammering one LDS bin
-__global__ __launch_bounds__(256) void k_stats(const uint8_t *__restrict__ lat, uint32_t n, uint32_t *__restrict__ hist,
-                                               unsigned long long *__restrict__ sums)
+// Batches: blockIdx.y = image; pointers into the latent tensor / the per-image workspace / the container
+// slots advance by the given byte strides (0 for single-image calls).
+template <typename T>
+__device__ __forceinline__ T *img_ptr(T *p, size_t stride)
 {
+    return (T *)((uint8_t *)p + (size_t)blockIdx.y * stride);
+}
+template <typename T>
+__device__ __forceinline__ const T *img_ptr(const T *p, size_t stride)
+{
+    return (const T *)((const uint8_t *)p + (size_t)blockIdx.y * stride);
+}
+
+__global__ __launch_bounds__(256) void k_stats(const uint8_t *__restrict__ lat_, uint32_t n, uint32_t *__restrict__ hist_,
+                                               unsigned long long *__restrict__ sums_, size_t s_lat, size_t s_ws)
+{
+    const uint8_t *lat = img_ptr(lat_, s_lat);
+    uint32_t *hist = img_ptr(hist_, s_ws);
+    unsigned long long *sums = img_ptr(sums_, s_ws);
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -139,10 +155,14 @@ __device__ __forceinline__ void ransw_build(RanswTab &t, const uint16_t *freq, i
     t.rcp[2 * lane + 1] = f1 ? (1.0f / (float)f1) * 0.99999988f : 0.f;
 }
 
-__global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__ lat, uint32_t n, uint32_t ns,
-                                                     const uint16_t *__restrict__ freq_g, uint8_t *__restrict__ scratch,
-                                                     uint32_t *__restrict__ lens)
+__global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__ lat_, uint32_t n, uint32_t ns,
+                                                     const uint16_t *__restrict__ freq_g_, uint8_t *__restrict__ scratch_,
+                                                     uint32_t *__restrict__ lens_, size_t s_lat, size_t s_ws)
 {
+    const uint8_t *lat = img_ptr(lat_, s_lat);
+    const uint16_t *freq_g = img_ptr(freq_g_, s_ws);
+    uint8_t *scratch = img_ptr(scratch_, s_ws);
+    uint32_t *lens = img_ptr(lens_, s_ws);
     __shared__ RanswTab tab;
     __shared__ __attribute__((aligned(16))) uint16_t words[WCAP / 2];
     const uint32_t st = blockIdx.x, lane = threadIdx.x;
@@ -199,10 +219,15 @@ __global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__
     if (lane == 0) lens[st] = (WCAP / 2 - pos) * 2;
 }
 
-__global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__ payload, const uint8_t *__restrict__ freq_bytes,
-                                                     const uint32_t *__restrict__ offsets, uint32_t n, uint32_t ns,
-                                                     uint8_t *__restrict__ lat, uint32_t *__restrict__ err)
+__global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__ payload_, const uint8_t *__restrict__ freq_bytes_,
+                                                     const uint32_t *__restrict__ offsets_, uint32_t n, uint32_t ns,
+                                                     uint8_t *__restrict__ lat_, uint32_t *__restrict__ err_, size_t s_slot,
+                                                     size_t s_ws, size_t s_lat)
 {
+    const uint8_t *payload = img_ptr(payload_, s_slot), *freq_bytes = img_ptr(freq_bytes_, s_slot);
+    const uint32_t *offsets = img_ptr(offsets_, s_ws);
+    uint8_t *lat = img_ptr(lat_, s_lat);
+    uint32_t *err = img_ptr(err_, s_ws);
     __shared__ RanswTab tab;
     __shared__ uint16_t freq[128];
     __shared__ uint8_t slot[4096];
@@ -299,10 +324,15 @@ __global__ __launch_bounds__(256) void k_rans_encode(const uint8_t *__restrict__
 // Exclusive prefix sum of `in[0..n)` into out[0..n], out[n] = total.  One workgroup of 1024 lanes:
 // wavefront-level scan with __shfl_up, wave totals combined through LDS, carry across chunks.
 // `in` may be unaligned container bytes (read byte-wise when `in_bytes` != nullptr).
-__global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ in, const uint8_t *__restrict__ in_bytes,
-                                               uint32_t n, uint32_t *__restrict__ out, uint8_t *__restrict__ table_out,
-                                               uint8_t *__restrict__ total_out)
+__global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ in_, const uint8_t *__restrict__ in_bytes_,
+                                               uint32_t n, uint32_t *__restrict__ out_, uint8_t *__restrict__ table_out_,
+                                               uint8_t *__restrict__ total_out_, size_t s_ws, size_t s_slot)
 {
+    const uint32_t *in = in_ ? img_ptr(in_, s_ws) : nullptr;
+    const uint8_t *in_bytes = in_bytes_ ? img_ptr(in_bytes_, s_slot) : nullptr;
+    uint32_t *out = img_ptr(out_, s_ws);
+    uint8_t *table_out = table_out_ ? img_ptr(table_out_, s_slot) : nullptr;
+    uint8_t *total_out = total_out_ ? img_ptr(total_out_, s_slot) : nullptr;
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry_s;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -351,9 +381,13 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ in, 
 }
 
 // one workgroup per stream: scratch tail -> payload
-__global__ __launch_bounds__(256) void k_compact(const uint8_t *__restrict__ scratch, const uint32_t *__restrict__ lens,
-                                                 const uint32_t *__restrict__ offsets, uint8_t *__restrict__ payload, uint32_t cap)
+__global__ __launch_bounds__(256) void k_compact(const uint8_t *__restrict__ scratch_, const uint32_t *__restrict__ lens_,
+                                                 const uint32_t *__restrict__ offsets_, uint8_t *__restrict__ payload_, uint32_t cap,
+                                                 size_t s_ws, size_t s_slot)
 {
+    const uint8_t *scratch = img_ptr(scratch_, s_ws);
+    const uint32_t *lens = img_ptr(lens_, s_ws), *offsets = img_ptr(offsets_, s_ws);
+    uint8_t *payload = img_ptr(payload_, s_slot);
     const uint32_t st = blockIdx.x, len = lens[st];
     const uint8_t *src = scratch + (size_t)st * cap + (cap - len);
     uint8_t *dst = payload + offsets[st];
@@ -514,7 +548,7 @@ extern "C" int sicn_codec_encode(int mode, const uint8_t *latent, uint32_t lat_w
 
     // statistics (also the checksum and the symbol-range check) -------------------------------
     HIP_TRY(hipMemsetAsync(w.hist, 0, 1024 + 64, stream));
-    if (n) hipLaunchKernelGGL(k_stats, dim3(min((n / 16 + 255u) / 256u + 1u, 128u)), dim3(256), 0, stream, latent, n, w.hist, w.sums);
+    if (n) hipLaunchKernelGGL(k_stats, dim3(min((n / 16 + 255u) / 256u + 1u, 128u)), dim3(256), 0, stream, latent, n, w.hist, w.sums, (size_t)0, (size_t)0);
     uint32_t hist[256];
     unsigned long long sums[2];
     HIP_TRY(hipMemcpyAsync(hist, w.hist, sizeof hist, hipMemcpyDeviceToHost, stream));
@@ -562,11 +596,11 @@ extern "C" int sicn_codec_encode(int mode, const uint8_t *latent, uint32_t lat_w
         uint8_t *table = out + SICN_CODEC_HEADER_BYTES + 256;
         uint8_t *payload = table + 4 * (size_t)ns;
         if (ns && mode == SICN_CODEC_RANSW)
-            hipLaunchKernelGGL(k_ransw_encode, dim3(ns), dim3(64), 0, stream, latent, n, ns, w.freq, w.scratch, w.lens);
+            hipLaunchKernelGGL(k_ransw_encode, dim3(ns), dim3(64), 0, stream, latent, n, ns, w.freq, w.scratch, w.lens, (size_t)0, (size_t)0);
         else if (ns)
             hipLaunchKernelGGL(k_rans_encode, dim3((ns + 255) / 256), dim3(256), 0, stream, latent, n, ns, w.freq, w.scratch, w.lens);
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, w.lens, (const uint8_t *)nullptr, ns, w.offsets, table, out + 40);
-        if (ns) hipLaunchKernelGGL(k_compact, dim3(ns), dim3(256), 0, stream, w.scratch, w.lens, w.offsets, payload, stream_cap(mode));
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, w.lens, (const uint8_t *)nullptr, ns, w.offsets, table, out + 40, (size_t)0, (size_t)0);
+        if (ns) hipLaunchKernelGGL(k_compact, dim3(ns), dim3(256), 0, stream, w.scratch, w.lens, w.offsets, payload, stream_cap(mode), (size_t)0, (size_t)0);
         uint32_t payload_bytes = 0;
         HIP_TRY(hipMemcpyAsync(&payload_bytes, w.offsets + ns, 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -621,13 +655,13 @@ extern "C" int sicn_codec_decode(const uint8_t *container, size_t bytes, uint8_t
             if (sum != 4096) return SICN_EINVAL;
         }
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, (const uint32_t *)nullptr, table, ns, w.offsets,
-                           (uint8_t *)nullptr, (uint8_t *)nullptr);
+                           (uint8_t *)nullptr, (uint8_t *)nullptr, (size_t)0, (size_t)0);
         uint32_t total = 0;
         HIP_TRY(hipMemcpyAsync(&total, w.offsets + ns, 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (total != info.payload_bytes) return SICN_EINVAL;
         if (ns && info.mode == SICN_CODEC_RANSW)
-            hipLaunchKernelGGL(k_ransw_decode, dim3(ns), dim3(64), 0, stream, payload, freq_bytes, w.offsets, n, ns, latent, err);
+            hipLaunchKernelGGL(k_ransw_decode, dim3(ns), dim3(64), 0, stream, payload, freq_bytes, w.offsets, n, ns, latent, err, (size_t)0, (size_t)0, (size_t)0);
         else if (ns)
             hipLaunchKernelGGL(k_rans_decode, dim3((ns + 255) / 256), dim3(256), 0, stream, payload, freq_bytes, w.offsets, n, ns, latent, err);
     }
@@ -637,10 +671,176 @@ extern "C" int sicn_codec_decode(const uint8_t *container, size_t bytes, uint8_t
     HIP_TRY(hipStreamSynchronize(stream));
     if (flag) return SICN_EINVAL;
     HIP_TRY(hipMemsetAsync(w.hist, 0, 1024 + 64, stream));
-    if (n) hipLaunchKernelGGL(k_stats, dim3(min((n / 16 + 255u) / 256u + 1u, 128u)), dim3(256), 0, stream, latent, n, w.hist, w.sums);
+    if (n) hipLaunchKernelGGL(k_stats, dim3(min((n / 16 + 255u) / 256u + 1u, 128u)), dim3(256), 0, stream, latent, n, w.hist, w.sums, (size_t)0, (size_t)0);
     unsigned long long sums[2];
     HIP_TRY(hipMemcpyAsync(sums, w.sums, sizeof sums, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     if (hipGetLastError() != hipSuccess) return SICN_ENODEV;
     return adler_from_sums(sums[0], sums[1], n) == info.adler32 ? SICN_OK : SICN_EBADMSG;
+}
+
+
+// ---- batches: the same containers, n images per call, two host synchronisations per call instead of
+// ---- three per image (statistics -> tables on the host; sizes / verdicts back at the end) ---------------
+extern "C" size_t sicn_codec_batch_workspace_bytes(int mode, uint32_t n_symbols, uint32_t n_images)
+{
+    return (size_t)n_images * align_up(sicn_codec_workspace_bytes(mode, n_symbols), 256);
+}
+
+extern "C" int sicn_codec_encode_batch(int mode, const uint8_t *latents, uint32_t n_images, uint32_t lat_w, uint32_t lat_h,
+                                       uint32_t lat_c, uint32_t img_w, uint32_t img_h, uint8_t *out, size_t slot_bytes,
+                                       size_t *out_bytes_host, void *workspace, size_t workspace_bytes, void *hip_stream)
+{
+    if (mode != SICN_CODEC_RANSW || !out || !out_bytes_host) return SICN_EINVAL;
+    const unsigned long long n64 = (unsigned long long)lat_w * lat_h * lat_c;
+    if (n64 > 0x7fffffffull || (n64 && !latents)) return SICN_EINVAL;
+    if (n_images == 0) return SICN_OK;
+    const uint32_t n = (uint32_t)n64, ns = (n + WSS - 1) / WSS;
+    if (slot_bytes < sicn_codec_max_bytes(mode, n) || (slot_bytes & 1)) return SICN_ENOSPC;
+    const size_t ws1 = align_up(sicn_codec_workspace_bytes(mode, n), 256);
+    if (!workspace || workspace_bytes < ws1 * n_images) return SICN_ENOSPC;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    std::vector<Workspace> w;
+    std::vector<uint32_t> hist;
+    std::vector<unsigned long long> sums;
+    std::vector<uint8_t> head;
+    std::vector<uint16_t> freq;
+    std::vector<uint32_t> payload_bytes;
+    try {
+        w.resize(n_images);
+        hist.resize((size_t)n_images * 256);
+        sums.resize((size_t)n_images * 2);
+        head.assign((size_t)n_images * (SICN_CODEC_HEADER_BYTES + 256), 0);
+        freq.assign((size_t)n_images * 128, 0);
+        payload_bytes.assign(n_images, 0);
+    } catch (const std::bad_alloc &) { return SICN_ENOMEM; }
+    for (uint32_t i = 0; i < n_images; i++) {
+        carve(w[i], (uint8_t *)workspace + i * ws1, ns, WCAP);
+        HIP_TRY(hipMemsetAsync(w[i].hist, 0, 1024 + 64, stream));
+    }
+    // one launch per stage for the whole batch (blockIdx.y = image): the images' streams run side by side
+    if (n)
+        hipLaunchKernelGGL(k_stats, dim3(min((n / 16 + 255u) / 256u + 1u, 128u), n_images), dim3(256), 0, stream, latents, n,
+                           w[0].hist, w[0].sums, (size_t)n, ws1);
+    for (uint32_t i = 0; i < n_images; i++) {
+        HIP_TRY(hipMemcpyAsync(&hist[(size_t)i * 256], w[i].hist, 1024, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&sums[(size_t)i * 2], w[i].sums, 16, hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (uint32_t i = 0; i < n_images; i++) {
+        const uint32_t *h = &hist[(size_t)i * 256];
+        for (int s = 128; s < 256; s++)
+            if (h[s]) return SICN_EINVAL;
+        uint8_t *hd = &head[(size_t)i * (SICN_CODEC_HEADER_BYTES + 256)];
+        std::memcpy(hd, "SICL", 4);
+        put16(hd + 4, 1);
+        put16(hd + 6, (uint32_t)mode);
+        put32(hd + 8, img_w);
+        put32(hd + 12, img_h);
+        put32(hd + 16, lat_w);
+        put32(hd + 20, lat_h);
+        put32(hd + 24, lat_c);
+        put32(hd + 28, n);
+        put32(hd + 32, ns);
+        put32(hd + 36, WSS);
+        put32(hd + 44, adler_from_sums(sums[(size_t)i * 2], sums[(size_t)i * 2 + 1], n));
+        uint16_t *f = &freq[(size_t)i * 128];
+        if (n && !normalize(h, n, f)) return SICN_EINVAL;
+        for (int s = 0; s < 128; s++) put16(hd + SICN_CODEC_HEADER_BYTES + 2 * s, f[s]);
+        uint8_t *o = out + (size_t)i * slot_bytes;
+        HIP_TRY(hipMemcpyAsync(o, hd, SICN_CODEC_HEADER_BYTES + 256, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(w[i].freq, f, 256, hipMemcpyHostToDevice, stream));
+    }
+    {
+        uint8_t *table = out + SICN_CODEC_HEADER_BYTES + 256, *payload = table + 4 * (size_t)ns;
+        if (ns)
+            hipLaunchKernelGGL(k_ransw_encode, dim3(ns, n_images), dim3(64), 0, stream, latents, n, ns, w[0].freq, w[0].scratch,
+                               w[0].lens, (size_t)n, ws1);
+        hipLaunchKernelGGL(k_scan, dim3(1, n_images), dim3(1024), 0, stream, w[0].lens, (const uint8_t *)nullptr, ns, w[0].offsets,
+                           table, out + 40, ws1, slot_bytes);
+        if (ns)
+            hipLaunchKernelGGL(k_compact, dim3(ns, n_images), dim3(256), 0, stream, w[0].scratch, w[0].lens, w[0].offsets, payload,
+                               WCAP, ws1, slot_bytes);
+    }
+    for (uint32_t i = 0; i < n_images; i++)
+        HIP_TRY(hipMemcpyAsync(&payload_bytes[i], w[i].offsets + ns, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (hipGetLastError() != hipSuccess) return SICN_ENODEV;
+    for (uint32_t i = 0; i < n_images; i++) out_bytes_host[i] = SICN_CODEC_HEADER_BYTES + 256 + 4 * (size_t)ns + payload_bytes[i];
+    return SICN_OK;
+}
+
+extern "C" int sicn_codec_decode_batch(const uint8_t *containers, size_t slot_bytes, const size_t *bytes_host, uint32_t n_images,
+                                       uint8_t *latents, size_t latent_stride, sicn_codec_info *infos_or_null, void *workspace,
+                                       size_t workspace_bytes, void *hip_stream)
+{
+    if (!containers || !bytes_host || (slot_bytes & 1)) return SICN_EINVAL;
+    if (n_images == 0) return SICN_OK;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    std::vector<uint8_t> head;
+    std::vector<sicn_codec_info> info;
+    std::vector<Workspace> w;
+    std::vector<uint32_t> flag, total;
+    std::vector<unsigned long long> sums;
+    try {
+        head.resize((size_t)n_images * (SICN_CODEC_HEADER_BYTES + 256));
+        info.resize(n_images);
+        w.resize(n_images);
+        flag.assign(n_images, 0);
+        total.assign(n_images, 0);
+        sums.assign((size_t)n_images * 2, 0);
+    } catch (const std::bad_alloc &) { return SICN_ENOMEM; }
+    const size_t hb = SICN_CODEC_HEADER_BYTES + 256;
+    for (uint32_t i = 0; i < n_images; i++) {
+        if (bytes_host[i] < hb || bytes_host[i] > slot_bytes) return SICN_EINVAL;
+        HIP_TRY(hipMemcpyAsync(&head[i * hb], containers + (size_t)i * slot_bytes, hb, hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    size_t ws1 = 0;
+    for (uint32_t i = 0; i < n_images; i++) {
+        int rc = sicn_codec_parse_header(&head[i * hb], SICN_CODEC_HEADER_BYTES, &info[i]);
+        if (rc) return rc;
+        if (info[i].mode != SICN_CODEC_RANSW) return SICN_EINVAL;
+        if (info[i].n_symbols != info[0].n_symbols || info[i].n_symbols > 0x7fffffffu) return SICN_EINVAL;
+        if (info[i].n_symbols && (!latents || latent_stride < info[i].n_symbols)) return SICN_ENOSPC;
+        const size_t fixed = hb + 4 * (size_t)info[i].n_streams;
+        if (bytes_host[i] < fixed + info[i].payload_bytes) return SICN_EINVAL;
+        uint32_t sum = 0;
+        for (int s = 0; s < 128; s++) sum += get16(&head[i * hb + SICN_CODEC_HEADER_BYTES + 2 * s]);
+        if (info[i].n_symbols && sum != 4096) return SICN_EINVAL;
+        if (infos_or_null) infos_or_null[i] = info[i];
+    }
+    const uint32_t n = info[0].n_symbols, ns = info[0].n_streams;
+    ws1 = align_up(sicn_codec_workspace_bytes(SICN_CODEC_RANSW, n), 256);
+    if (!workspace || workspace_bytes < ws1 * n_images) return SICN_ENOSPC;
+    for (uint32_t i = 0; i < n_images; i++) {
+        carve(w[i], (uint8_t *)workspace + i * ws1, ns, 0);
+        HIP_TRY(hipMemsetAsync(w[i].hist, 0, 1024 + 64, stream));
+    }
+    {   // one launch per stage for the whole batch (blockIdx.y = image)
+        const uint8_t *freq_bytes = containers + SICN_CODEC_HEADER_BYTES, *table = freq_bytes + 256, *payload = table + 4 * (size_t)ns;
+        hipLaunchKernelGGL(k_scan, dim3(1, n_images), dim3(1024), 0, stream, (const uint32_t *)nullptr, table, ns, w[0].offsets,
+                           (uint8_t *)nullptr, (uint8_t *)nullptr, ws1, slot_bytes);
+        if (ns)
+            hipLaunchKernelGGL(k_ransw_decode, dim3(ns, n_images), dim3(64), 0, stream, payload, freq_bytes, w[0].offsets, n, ns,
+                               latents, w[0].hist + 255, slot_bytes, ws1, latent_stride);
+    }
+    for (uint32_t i = 0; i < n_images; i++) {
+        HIP_TRY(hipMemcpyAsync(&total[i], w[i].offsets + ns, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&flag[i], w[i].hist + 255, 4, hipMemcpyDeviceToHost, stream));
+    }
+    // checksums (the flags were read back in stream order before the statistics block is reused)
+    for (uint32_t i = 0; i < n_images; i++) HIP_TRY(hipMemsetAsync(w[i].hist, 0, 1024 + 64, stream));
+    if (n)
+        hipLaunchKernelGGL(k_stats, dim3(min((n / 16 + 255u) / 256u + 1u, 128u), n_images), dim3(256), 0, stream, latents, n,
+                           w[0].hist, w[0].sums, latent_stride, ws1);
+    for (uint32_t i = 0; i < n_images; i++)
+        HIP_TRY(hipMemcpyAsync(&sums[(size_t)i * 2], w[i].sums, 16, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (hipGetLastError() != hipSuccess) return SICN_ENODEV;
+    for (uint32_t i = 0; i < n_images; i++) {
+        if (flag[i] || total[i] != info[i].payload_bytes) return SICN_EINVAL;
+        if (adler_from_sums(sums[(size_t)i * 2], sums[(size_t)i * 2 + 1], n) != info[i].adler32) return SICN_EBADMSG;
+    }
+    return SICN_OK;
 }

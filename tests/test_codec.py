@@ -173,3 +173,26 @@ def test_gpu_codec_on_real_latent_and_errors():
     with pytest.raises(_lib.SicnError) as e:
         codec.decode_latent(corrupt)
     assert e.value.code in (-22, -74)
+
+
+@gpu
+def test_gpu_batch_equals_single_calls_and_oracle():
+    """sicn_codec_encode_batch / decode_batch: container i is byte-identical to the single-image call and to the
+    oracle; decode_batch inverts it; a corrupted member is reported."""
+    import torch
+    from simple_image_compression_network_amd import _lib, codec
+    rng = np.random.default_rng(21)
+    lat = np.stack([_mock_latent(rng, (9, 10, 192), zero_frac=z) for z in (0.5, 0.1, 0.9, 0.0, 1.0)])
+    dev = torch.from_numpy(lat).cuda()
+    slots, sizes = codec.encode_latents(dev, 160, 144)
+    for i in range(lat.shape[0]):
+        blob = slots[i, :sizes[i]].cpu().numpy().tobytes()
+        assert blob == c_oracle.codec_encode(lat[i], (160, 144), 3)
+        assert blob == codec.encode_latent(dev[i], 160, 144, codec.RANSW).cpu().numpy().tobytes()
+    back, infos = codec.decode_latents(slots, sizes)
+    assert torch.equal(back, dev) and all(i.mode == 3 and i.lat_c == 192 for i in infos)
+    bad = slots.clone()
+    bad[2, sizes[2] - 3] ^= 0x04
+    with pytest.raises(_lib.SicnError) as e:
+        codec.decode_latents(bad, sizes)
+    assert e.value.code in (-22, -74)

@@ -34,3 +34,21 @@ for mode, name in ((codec.RAW8, "raw8"), (codec.PACKED7, "packed7"), (codec.RANS
     td = (time.perf_counter() - t0) / 20
     print(f"{name:8s}: {n} symbols -> {c.numel()} bytes ({8 * c.numel() / n:.2f} bit/symbol); "
           f"encode {te * 1e3:.3f} ms ({n / te / 1e9:.2f} Gsym/s), decode {td * 1e3:.3f} ms ({n / td / 1e9:.2f} Gsym/s)  [host-synchronous calls]")
+
+# batches: 8 latents per call
+lat8 = lat0[None].repeat(8, 1, 1, 1).contiguous()
+slots, sizes = codec.encode_latents(lat8, W, H)
+back, _ = codec.decode_latents(slots, sizes)
+torch.cuda.synchronize()
+assert torch.equal(back, lat8)
+t0 = time.perf_counter()
+for _ in range(10):
+    slots, sizes = codec.encode_latents(lat8, W, H)
+torch.cuda.synchronize()
+te = (time.perf_counter() - t0) / 10
+t0 = time.perf_counter()
+for _ in range(10):
+    codec.decode_latents(slots, sizes)
+torch.cuda.synchronize()
+td = (time.perf_counter() - t0) / 10
+print(f"rANS-W batch of 8: encode {te * 1e3:.3f} ms ({8 * n / te / 1e9:.2f} Gsym/s), decode {td * 1e3:.3f} ms ({8 * n / td / 1e9:.2f} Gsym/s)")
