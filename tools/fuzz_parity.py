@@ -18,6 +18,7 @@ from simple_image_compression_network_amd.config import LayerDesc  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=200)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--big", action="store_true", help="image sizes up to 600 x 400 (slow on the CPU side)")
 ap.add_argument("--chains", type=int, default=0, help="additionally: whole 8-layer chains (internal layouts) on random sizes")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
@@ -28,8 +29,8 @@ bad = 0
 for case in range(args.cases):
     cin, cout, simd, pe, tr = FAMILIES[rng.integers(len(FAMILIES))]
     big = rng.random() < 0.25
-    w = int(rng.integers(1, 200 if big else 70))
-    h = int(rng.integers(1, 120 if big else 40))
+    w = int(rng.integers(1, 600 if args.big else 200 if big else 70))
+    h = int(rng.integers(1, 400 if args.big else 120 if big else 40))
     if cin == 3:
         w, h = w * 2 + int(rng.integers(2)), h * 2 + int(rng.integers(2))
     n = int(rng.integers(1, 4))
