@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fills BASELINE.md §4: every BASELINE.json config on this box — CPU dataflow port (1 thread), CPU
 direct closed form (all host threads, OpenMP), 1 GPU — with MFMA / HBM roofline fractions and
-bit-exactness flags.  Run on the GPU box: python tools/results_table.py > gpurun_out/results.json"""
+bit-exactness flags.  Run on the GPU box: python tests/results_table.py > gpurun_out/results.json"""
 import hashlib
 import json
 import os

@@ -431,9 +431,9 @@ def test_capture_helper_replays(api):
 
 
 def test_randomised_sweep_small():
-    """tools/fuzz_parity.py (every kernel family + whole chains on random sizes, strip cuts and tile widths) — a
+    """tests/fuzz_parity.py (every kernel family + whole chains on random sizes, strip cuts and tile widths) — a
     short seeded run in a child process; the long runs are manual."""
-    r = subprocess.run([sys.executable, str(ROOT / "tools" / "fuzz_parity.py"), "--cases", "60", "--seed", "3", "--chains", "4"],
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "fuzz_parity.py"), "--cases", "60", "--seed", "3", "--chains", "4"],
                        capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "60/60 cases bit-exact" in r.stdout and "4/4 chains bit-exact" in r.stdout
