@@ -119,7 +119,9 @@ __device__ __forceinline__ void pass16(v4i (&acc)[Geo<TX>::NC][NT16], const uint
     else
         wait_vmcnt<VMCNT>();
 #endif
+#ifndef SICN_EXP_NO_PASS_BARRIER   // timing experiment only (races): what does the per-pass barrier cost?
     block_barrier();
+#endif
 }
 
 // Always issues NC * NT16/4 stores per wave (positions outside the image go to an out-of-range offset
