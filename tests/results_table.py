@@ -16,7 +16,7 @@ import torch
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from oracle import c_oracle  # noqa: E402  (CPU baseline + checker)
-from simple_image_compression_network_amd import api  # noqa: E402
+from simple_image_compression_network_amd import api, codec  # noqa: E402
 from simple_image_compression_network_amd.config import eight_layer_descs  # noqa: E402
 
 HASH = json.loads((ROOT / "tests/golden/appendix_a_hashes.json").read_text())["layers"]
@@ -45,6 +45,23 @@ def cpu_net(descs, x, form, threads, first=0, last=7):
     t0 = time.perf_counter()
     outs = c_oracle.run_net(descs[first:last + 1], WORDS[first:last + 1], BIAS[first:last + 1], x, form, threads)
     return time.perf_counter() - t0, outs
+
+
+def with_coder(net, xg, w, h):
+    """encode (L0-L3 -> rANS-W containers) then decode (containers -> latent -> L4-L7); returns (seconds per pass,
+    bits per pixel, round trip exact).  The coder is this project's own (no reference counterpart)."""
+    def one():
+        lat, _ = net.run_layers(0, 3, xg)
+        slots, sizes = codec.encode_latents(lat, w, h)
+        back, _ = codec.decode_latents(slots, sizes)
+        rec, _ = net.run_layers(4, 7, back)
+        return lat, back, sizes, rec
+    lat, back, sizes, rec = one()
+    torch.cuda.synchronize()
+    t = gpu_time(one, reps=10)
+    ref, _ = net.forward(xg)
+    torch.cuda.synchronize()
+    return t, 8.0 * sum(sizes) / (xg.shape[0] * w * h), bool(torch.equal(back, lat) and torch.equal(rec, ref))
 
 
 def fracs(descs, first, last, n_img, secs):
@@ -90,8 +107,10 @@ out_g = torch.empty((1,) + net.descs[-1].out_shape, dtype=torch.uint8, device="c
 lat_g = torch.empty((1,) + net.descs[3].out_shape, dtype=torch.uint8, device="cuda")
 t_g = gpu_time(lambda: net.forward(xg, out_g, lat_g))
 m, h = fracs(d, 0, 7, 1, t_g)
+t_c, bpp, rt = with_coder(net, xg, 1920, 1080)
 rows.append({"config": "3: 1920x1080 encode+decode", "pixels": 1920 * 1080, "cpu_dataflow_1thr_Mpx_s": None,
              "cpu_direct_Mpx_s": 1920 * 1080 / t_dr / 1e6, "gpu1_Mpx_s": 1920 * 1080 / t_g / 1e6, "mfma_frac": m, "hbm_frac": h,
+             "gpu1_with_ransw_coder_Mpx_s": 1920 * 1080 / t_c / 1e6, "coded_bits_per_pixel": bpp, "coder_round_trip_exact": rt,
              "latent_bit_exact": bool(np.array_equal(lat_g[0].cpu().numpy(), o_dr[3])),
              "output_bit_exact": bool(np.array_equal(out_g[0].cpu().numpy(), o_dr[7]))})
 # ---- config 4 (one GPU's shard): 8 x 4K encode + decode ----------------------------------------
@@ -104,7 +123,9 @@ out = torch.empty((8, 2160, 3840, 3), dtype=torch.uint8, device="cuda")
 lat = torch.empty((8, 135, 240, 192), dtype=torch.uint8, device="cuda")
 t_g = gpu_time(lambda: net.forward(xg, out, lat), reps=10)
 m, h = fracs(d, 0, 7, 8, t_g)
+t_c, bpp, rt = with_coder(net, xg, 3840, 2160)
 rows.append({"config": "4: 8 x 3840x2160 encode+decode on ONE GPU (1/8 of the 64-image batch)", "pixels": 8 * 3840 * 2160,
+             "gpu1_with_ransw_coder_Mpx_s": 8 * 3840 * 2160 / t_c / 1e6, "coded_bits_per_pixel": bpp, "coder_round_trip_exact": rt,
              "cpu_dataflow_1thr_Mpx_s": None, "cpu_direct_Mpx_s": 3840 * 2160 / t_dr / 1e6, "gpu1_Mpx_s": 8 * 3840 * 2160 / t_g / 1e6,
              "mfma_frac": m, "hbm_frac": h, "latent_bit_exact": bool(np.array_equal(lat[0].cpu().numpy(), o_dr[3])),
              "output_bit_exact": bool(np.array_equal(out[0].cpu().numpy(), o_dr[7]))})
