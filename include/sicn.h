@@ -35,8 +35,10 @@
  * after creation; concurrent launches on different streams are allowed provided each uses its own
  * workspace.
  *
- * Size limits of the specialised kernels (SICN_EINVAL beyond them): one image's input < 2 GiB and
- * output < 4 GiB per layer (32-bit offsets inside an image; 8K RGB images fit), n_images <= 65535.
+ * Size limits of the specialised kernels (SICN_EINVAL beyond them): one image's input and output
+ * < 2 GiB per layer (31-bit offsets inside an image: loads and stores go through buffer descriptors
+ * whose range check is the padding / masking; 8K RGB images fit: 8192 x 4320 x 128 B / 4 = 1.1 GB at
+ * layer 0's output), the RGB input tensor of a batch < 2 GiB, n_images <= 65535.
  *
  * Naming trap inherited from the reference: IFM_ROW / OFM_ROW are WIDTHS (x, fast dimension),
  * IFM_COL / OFM_COL are HEIGHTS (conv_nonsquare_top.cpp:283-285).
