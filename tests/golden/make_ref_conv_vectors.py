@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Golden vectors produced by REFERENCE CODE compiled in the build container.
+
+Runs oracle/_ref/libsicn_refconv.so — oracle/ref_harness.cpp around the reference's own golden
+convolution `conv_nonsquare<>` (/root/reference/conv.hpp:91-123, included unmodified; built by
+`make -C oracle ref`) — and writes
+
+  tests/golden/ref_conv_vectors.npz   seeded random layers (random nibble weights, biases, pixels >= 128,
+                                      odd sizes, Cin/Cout in {3,128,192}): for case k: d{k} (LayerDesc
+                                      fields), words{k} (FixedPointWeights tiles), bias{k}, x{k}, y{k}
+  tests/golden/ref_conv_hashes.json   SHA-256 of all 8 layer outputs of eight_layers_net (PARAM weights)
+                                      for rng256 / ones768 / rng768, each layer computed by conv_nonsquare
+                                      exactly as the reference testbench verifies it
+
+This script is the only user of oracle/_ref; it needs /root/reference and therefore runs only in the
+build container.  The two files it writes are data (inputs and expected outputs) and travel to the GPU box.
+
+What is reference code here and what is restated:
+  * the 7-deep convolution loop, its index order and its 8-bit wrapping accumulation: reference
+    (conv.hpp:91-123), TI/TO/TW = uint8_t/int8_t/int8_t for ap_uint<8>/ap_int<8>/ap_int<4>;
+  * `output += BIAS; if (output < 0) output = 0`: restated in ref_harness.cpp from conv3_nonsquare_tb.cpp:616-627;
+  * the padded input map (tb:581-600) and the zero-stuffed deconv map (tb:700-718): restated below;
+  * the FixedPointWeights tile -> W[o][kx][ky][c] walk (tb:546-571): restated below (`tb_unpack_weights`),
+    a literal transcription of the testbench's counter walk, NOT the oracle's vectorised unpack.
+The dataflow half of the oracle (sliding-window FSM, MVAU fold order) has no reference-compiled anchor:
+conv_nonsquare_top.cpp needs the Vivado-HLS headers.
+"""
+import ctypes
+import hashlib
+import json
+import sys
+import time
+from dataclasses import astuple
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.path.insert(0, str(ROOT))
+from simple_image_compression_network_amd.config import LayerDesc, NET_CHANNELS  # noqa: E402
+
+LIB = ctypes.CDLL(str(ROOT / "oracle" / "_ref" / "libsicn_refconv.so"))
+LIB.sicn_refconv_dims.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+LIB.sicn_refconv_run.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4
+
+
+def _dims(case_id):
+    d = (ctypes.c_int * 7)()
+    assert LIB.sicn_refconv_dims(case_id, d) == 0, case_id
+    return tuple(d)
+
+
+def padded_map(x, transposed):
+    """x [H][W][C] -> the testbench's input_padding[x][y][c] (index order x FIRST).
+    conv (tb:581-600): 2-pixel zero border.  deconv (tb:700-718): size 2W+4 x 2H+4, zero where
+    ox < 2 | ox >= 2W+2 | (ox-1) even (same for y), else input[(ox-2)/2][(oy-2)/2]."""
+    h, w, c = x.shape
+    if not transposed:
+        p = np.zeros((w + 4, h + 4, c), np.uint8)
+        p[2:2 + w, 2:2 + h] = x.transpose(1, 0, 2)
+        return p
+    p = np.zeros((2 * w + 4, 2 * h + 4, c), np.uint8)
+    for ox in range(2 * w + 4):
+        if ox < 2 or ox >= 2 * w + 2 or (ox + 1 - 2) % 2 == 0:
+            continue
+        for oy in range(2 * h + 4):
+            if oy < 2 or oy >= 2 * h + 2 or (oy + 1 - 2) % 2 == 0:
+                continue
+            p[ox, oy] = x[(oy - 2) // 2, (ox - 2) // 2]
+    return p
+
+
+def tb_unpack_weights(words, simd, pe, cin, cout):
+    """conv3_nonsquare_tb.cpp:546-571 transcribed: words[PE][TILES] -> W[o][kx][ky][c] (int8).
+    `weights(tile)[pe][simd]` = sign-extended nibble `simd` of m_weights[pe][tile] (weights.hpp:134-139)."""
+    tx, ty = (cin * 25) // simd, cout // pe
+    W = np.zeros((cout, 5, 5, cin), np.int8)
+    kx = ky = chan = 0
+    for p in range(pe):
+        o = p
+        for oy in range(ty):
+            for ox in range(tx):
+                word = int(words[p][oy * tx + ox])
+                for s in range(simd):
+                    n = (word >> (4 * s)) & 15
+                    W[o, kx, ky, chan] = n - 16 if n > 7 else n
+                    chan += 1
+                    if chan == cin:
+                        chan = 0
+                        kx += 1
+                        if kx == 5:
+                            kx = 0
+                            ky += 1
+                            if ky == 5:
+                                ky = 0
+                                o += pe
+                                if o == cout:
+                                    o = 0
+    return W
+
+
+def ref_layer(case_id, x, words, bias, simd, pe, transposed):
+    """One layer through the reference's conv_nonsquare. x [H][W][Cin] uint8 -> [OH][OW][Cout] uint8."""
+    ix, iy, ox, oy, ci, co, s = _dims(case_id)
+    h, w, c = x.shape
+    assert c == ci and s == (1 if transposed else 2)
+    assert (ix, iy) == ((2 * w + 4, 2 * h + 4) if transposed else (w + 4, h + 4)), (case_id, ix, iy, x.shape)
+    assert (ox, oy) == ((2 * w, 2 * h) if transposed else ((w + 1) // 2, (h + 1) // 2))
+    img = np.ascontiguousarray(padded_map(x, transposed))
+    W = np.ascontiguousarray(tb_unpack_weights(words, simd, pe, ci, co))
+    b = np.ascontiguousarray(bias, dtype=np.int8)
+    out = np.zeros((ox, oy, co), np.int8)
+    rc = LIB.sicn_refconv_run(case_id, img.ctypes.data, W.ctypes.data, b.ctypes.data, out.ctypes.data)
+    assert rc == 0
+    assert out.min() >= 0
+    return np.ascontiguousarray(out.transpose(1, 0, 2)).view(np.uint8)
+
+
+def pack_words(W_okkc, simd, pe):
+    """Inverse walk of tb_unpack_weights for W[o][ky][kx][c] nibbles -> words [PE][TILES] (uint64)."""
+    cout, _, _, cin = W_okkc.shape
+    sf, nf = 25 * cin // simd, cout // pe
+    flat = W_okkc.reshape(cout, 25 * cin).astype(np.int64) & 15          # k = (ky*5+kx)*Cin + c
+    words = np.zeros((pe, nf * sf), np.uint64)
+    for p in range(pe):
+        for n in range(nf):
+            row = flat[n * pe + p].reshape(sf, simd)
+            words[p, n * sf:(n + 1) * sf] = (row.astype(np.uint64) << (np.arange(simd, dtype=np.uint64) * np.uint64(4))).sum(1)
+    return words
+
+
+SMALL = [  # case id, Cin, Cout, SIMD, PE, W, H, transposed
+    (0, 3, 128, 3, 8, 24, 16, 0), (1, 3, 128, 3, 8, 21, 17, 0), (2, 128, 128, 8, 16, 20, 16, 0),
+    (3, 128, 192, 8, 24, 19, 17, 0), (4, 192, 128, 12, 16, 6, 4, 1), (5, 128, 128, 8, 16, 5, 5, 1),
+    (6, 128, 3, 8, 3, 9, 6, 1)]
+
+
+def main():
+    out = {}
+    for k, (cid, cin, cout, simd, pe, w, h, tr) in enumerate(SMALL):
+        rng = np.random.default_rng(7000 + k)
+        ow, oh = (2 * w, 2 * h) if tr else ((w + 1) // 2, (h + 1) // 2)
+        d = LayerDesc(IFM_CH=cin, IFM_ROW=w, IFM_COL=h, OFM_CH=cout, OFM_ROW=ow, OFM_COL=oh, SIMD=simd, PE=pe,
+                      W_TILES=(cout // pe) * (25 * cin // simd), transposed=tr)
+        d.validate()
+        W = rng.integers(-8, 8, (cout, 5, 5, cin)).astype(np.int8)
+        b = rng.integers(-128, 128, cout).astype(np.int8)
+        x = rng.integers(0, 256, (h, w, cin), dtype=np.uint8)
+        words = pack_words(W, simd, pe)
+        y = ref_layer(cid, x, words, b, simd, pe, tr)
+        out[f"d{k}"] = np.array(astuple(d), dtype=np.int32)
+        out[f"words{k}"] = words.astype(np.uint32) if simd <= 8 else words
+        out[f"bias{k}"] = b
+        out[f"x{k}"] = x
+        out[f"y{k}"] = y
+        print(f"case {k}: {'deconv' if tr else 'conv'} {w}x{h} {cin}->{cout} sha {hashlib.sha256(y.tobytes()).hexdigest()[:16]}")
+    np.savez_compressed(HERE / "ref_conv_vectors.npz", **out)
+
+    # whole net, PARAM weights, every layer through conv_nonsquare as conv3_nonsquare_tb.cpp:861-1056 does
+    z = np.load(HERE / "param_weights.npz")
+    inputs = {"rng256": (10, np.random.default_rng(0).integers(0, 256, (256, 256, 3), dtype=np.uint8)),
+              "ones768": (20, np.ones((512, 768, 3), np.uint8)),
+              "rng768": (20, np.random.default_rng(0).integers(0, 256, (512, 768, 3), dtype=np.uint8))}
+    only = sys.argv[1:]  # optionally restrict to some inputs
+    hashes = {"provenance": "conv_nonsquare<> of /root/reference/conv.hpp:91-123 compiled unmodified "
+                            "(oracle/ref_harness.cpp, g++ -O2), PARAM weights, layer by layer as "
+                            "conv3_nonsquare_tb.cpp:861-1056; made by tests/golden/make_ref_conv_vectors.py",
+              "inputs": {}, "layers": {}}
+    prev = HERE / "ref_conv_hashes.json"
+    if prev.exists():
+        old = json.loads(prev.read_text())
+        hashes["inputs"].update(old.get("inputs", {}))
+        hashes["layers"].update(old.get("layers", {}))
+    for name, (base, x) in inputs.items():
+        if only and name not in only:
+            continue
+        hashes["inputs"][name] = hashlib.sha256(x.tobytes()).hexdigest()
+        hs = []
+        for n, (cin, cout, simd, pe, tr) in enumerate(NET_CHANNELS):
+            t0 = time.time()
+            x = ref_layer(base + n, x, z[f"w{n}_words"], z[f"b{n}"], simd, pe, tr)
+            hs.append(hashlib.sha256(x.tobytes()).hexdigest())
+            print(f"{name} L{n}: {x.shape} {time.time() - t0:.1f}s {hs[-1][:16]}", flush=True)
+        hashes["layers"][name] = hs
+    prev.write_text(json.dumps(hashes, indent=1) + "\n")
+    app = json.loads((HERE / "appendix_a_hashes.json").read_text())
+    for name, hs in hashes["layers"].items():
+        print(name, "== SURVEY Appendix A:", hs == app["layers"][name])
+
+
+if __name__ == "__main__":
+    main()

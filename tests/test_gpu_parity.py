@@ -382,6 +382,19 @@ def test_committed_small_vectors_on_gpu(api):
         assert np.array_equal(got[0], y), d
 
 
+def test_reference_compiled_vectors_on_gpu(api):
+    """The HIP path against tests/golden/ref_conv_vectors.npz, whose expected outputs were computed by the
+    reference's own conv_nonsquare<> (conv.hpp:91-123, compiled unmodified in the build container; see
+    tests/golden/make_ref_conv_vectors.py). No oracle call: reference-made bytes vs GPU bytes."""
+    from test_oracle_golden import _small_vectors
+    n = 0
+    for d, words, bias, x, y in _small_vectors("ref_conv_vectors.npz"):
+        got = _run_layer(api, d, words, bias, x[None])
+        assert np.array_equal(got[0], y), d
+        n += 1
+    assert n == 7
+
+
 def test_forward_is_graph_capturable(api):
     """sicn.h promises that launch functions neither allocate nor synchronise: capture the 8-layer chain into a
     hipGraph (torch.cuda.CUDAGraph), replay it on new input and compare with the eager result."""

@@ -151,9 +151,9 @@ def test_oracle_rejects_bad_descs(param_words):
                            np.zeros(d.in_shape, np.uint8), "direct")
 
 
-def _small_vectors():
+def _small_vectors(name="small_vectors.npz"):
     from dataclasses import fields
-    z = np.load(GOLDEN / "small_vectors.npz")
+    z = np.load(GOLDEN / name)
     k = 0
     while f"d{k}" in z:
         d = LayerDesc(**{f.name: int(v) for f, v in zip(fields(LayerDesc), z[f"d{k}"])})
@@ -167,6 +167,41 @@ def test_committed_small_vectors_still_hold():
     n = 0
     for d, words, bias, x, y in _small_vectors():
         for form in ("dataflow_im2col", "naive", "direct"):
+            assert np.array_equal(c_oracle.run_layer(d, words, bias, x, form), y), (d, form)
+        n += 1
+    assert n == 7
+
+
+# ---- fixtures made by REFERENCE code: conv_nonsquare<> of /root/reference/conv.hpp:91-123, compiled unmodified
+# ---- (oracle/ref_harness.cpp -> oracle/_ref, tests/golden/make_ref_conv_vectors.py). Only the data travels.
+REF_HASHES = json.loads((GOLDEN / "ref_conv_hashes.json").read_text())
+
+
+def test_reference_compiled_hashes_cover_appendix_a():
+    """All 24 known answers of SURVEY Appendix A were re-made here by the reference's own golden convolution
+    (layer by layer as conv3_nonsquare_tb.cpp:861-1056 does): the oracle's pin is reference code, not the survey."""
+    assert REF_HASHES["inputs"] == {k: v["sha256"] for k, v in HASHES["inputs"].items()}
+    for name in ("ones768", "rng768", "rng256"):
+        assert REF_HASHES["layers"][name] == HASHES["layers"][name], name
+
+
+@pytest.mark.parametrize("name", ["ones768", "rng768", "rng256"])
+def test_closed_form_matches_reference_compiled_hashes(name, param_closed_form):
+    outs = sicn_ref.eight_layers_net_ref(_input(name), param_closed_form)
+    assert [_sha(o) for o in outs] == REF_HASHES["layers"][name]
+
+
+def test_every_oracle_form_matches_reference_compiled_vectors():
+    """tests/golden/ref_conv_vectors.npz: seeded random nibble weights / biases / pixels >= 128, odd sizes,
+    Cin/Cout in {3,128,192}, outputs computed by the reference's conv_nonsquare<> on the testbench's padded /
+    zero-stuffed maps (conv3_nonsquare_tb.cpp:581-600,700-718). Random weights differ per PE, so a channel or
+    SIMD-lane permutation in the oracle's tile unpack would show here (the PARAM tables cannot show it)."""
+    n = 0
+    for d, words, bias, x, y in _small_vectors("ref_conv_vectors.npz"):
+        w = sicn_ref.unpack_finn_tiles(words, d.SIMD, d.PE, d.IFM_CH, d.OFM_CH)
+        got = (sicn_ref.deconv522_ref if d.transposed else sicn_ref.conv2d_ref)(x, w, bias)
+        assert np.array_equal(got, y), (d, "numpy closed form")
+        for form in ("dataflow", "dataflow_im2col", "naive", "direct"):
             assert np.array_equal(c_oracle.run_layer(d, words, bias, x, form), y), (d, form)
         n += 1
     assert n == 7
