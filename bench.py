@@ -9,18 +9,30 @@ conv_nonsquare_top.cpp:295-357) on synthetic 4K RGB images, one process per GPU.
 A "step" = one pass of the hot path over this rank's batch of IMAGES_PER_GPU 3840x2160x3 uint8
 images, already resident in HBM (BASELINE.json configs[3]: 64 images over 8 GPUs = 8 per GPU; weak
 scaling: every rank always owns 8 images, no data-path collective — images are independent).
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel, timed live with hipEvents
-recorded by the library on the launch stream (sicn_net_profile); `cpu_baseline` is the oracle's
-dataflow-faithful C port (the stand-in for the reference's HLS C-simulation, which needs Vivado
-headers) timed on this host on a bounded crop of the same workload.
+Rank 0 prints ONE JSON line:
+
+  value / ms_per_step   the timed transform (headline, as BASELINE.json's metric)
+  output_bit_exact      SHA-256 of every rank's latents and reconstructions of the TIMED run against
+                        tests/golden/bench_4k_hashes.json (made by the oracle, tests/golden/make_bench_hashes.py)
+  rank_checksums        adler32 of each rank's output batch, gathered on rank 0 (every shard ran, shards differ)
+  roofline              the dominant kernel, timed live with hipEvents recorded by the library on the launch
+                        stream (sicn_net_profile); `traffic` is the PMC figure of profiles/<round>_pmc_summary.json
+                        and is only reported while that file's kernel-source fingerprint matches this build
+  with_coder            secondary: analysis -> rANS-W encode -> decode -> synthesis (the coder is this project's own;
+                        the reference has none), timed the same way
+  cpu_baseline          the oracle's dataflow-faithful C port (1 thread, crop) — the stand-in for the reference's HLS
+                        C-simulation, which needs Vivado headers — plus `all_cores`: the oracle's OpenMP direct form
+                        on one whole 4K image, whose bytes are also compared with the GPU's image 0
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
+import zlib
 from pathlib import Path
 
 import numpy as np
@@ -30,6 +42,15 @@ sys.path.insert(0, str(ROOT))
 
 PEAK_INT8_TOPS = 5000.0   # dense int8 MFMA = 2x the ~2.5 PFLOP/s bf16 dense peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0     # HBM3E spec
+KERNEL_SOURCES = ("k_common.hpp", "k_mfma16.hip", "k_mfma.hip", "k_rgb.hip", "k_generic.hip", "sicn_abi.hip")
+
+
+def kernel_source_fingerprint() -> str:
+    """Identifies the kernel build a PMC summary belongs to (so a stale `traffic` is never reported)."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        h.update((ROOT / "simple_image_compression_network_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -41,6 +62,7 @@ def parse():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--images-per-gpu", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-coder", action="store_true", help="skip the secondary with_coder measurement")
     ap.add_argument("--cpu-sample", type=int, nargs=2, default=[256, 256], metavar=("W", "H"))
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank) is the real thing; gloo lets several ranks share one GPU "
@@ -48,22 +70,35 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(image0: np.ndarray, sample_wh):
-    """Oracle (test infrastructure) used ONLY as the reported CPU baseline: stage-by-stage dataflow
-    port, one thread, on a crop of the first synthetic image."""
+def cpu_baseline(image0: np.ndarray, sample_wh, gpu_latent0, gpu_out0):
+    """Oracle (test infrastructure) used ONLY as the reported CPU baseline and as checker of image 0."""
     from oracle import c_oracle
     from simple_image_compression_network_amd.config import eight_layer_descs
     w, h = sample_wh
     z = np.load(ROOT / "tests" / "golden" / "param_weights.npz")
+    words, bias = [z[f"w{n}_words"] for n in range(8)], [z[f"b{n}"] for n in range(8)]
     crop = np.ascontiguousarray(image0[:h, :w])
-    descs = eight_layer_descs(w, h)
     t0 = time.perf_counter()
-    c_oracle.run_net(descs, [z[f"w{n}_words"] for n in range(8)], [z[f"b{n}"] for n in range(8)], crop, "dataflow")
+    c_oracle.run_net(eight_layer_descs(w, h), words, bias, crop, "dataflow")
     dt = time.perf_counter() - t0
-    return {"value": round(w * h / dt / 1e6, 6), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-            "sample": f"top-left {w}x{h} crop of image 0, all 8 layers, oracle/sicn_oracle.c dataflow form "
-                      f"(pad -> sliding-window FSM -> decimate -> folded 8-bit-wrapping MVAU -> bias/ReLU), "
-                      f"1 thread, {dt:.1f} s"}
+    res = {"value": round(w * h / dt / 1e6, 6), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+           "sample": f"top-left {w}x{h} crop of image 0, all 8 layers, oracle/sicn_oracle.c dataflow form "
+                     f"(pad -> sliding-window FSM -> decimate -> folded 8-bit-wrapping MVAU -> bias/ReLU), "
+                     f"1 thread, {dt:.1f} s"}
+    # all host cores this process may use: OpenMP direct closed form on the whole image 0
+    try:
+        nproc = len(os.sched_getaffinity(0))
+    except AttributeError:
+        nproc = os.cpu_count() or 1
+    H, W = image0.shape[:2]
+    t0 = time.perf_counter()
+    outs = c_oracle.run_net(eight_layer_descs(W, H), words, bias, image0, "direct", threads=nproc)
+    dt = time.perf_counter() - t0
+    res["all_cores"] = {"value": round(W * H / dt / 1e6, 4), "unit": "Mpixels/s", "cores": nproc, "nproc": os.cpu_count(),
+                        "kind": "port", "sample": f"whole image 0 ({W}x{H}), all 8 layers, oracle direct closed form, "
+                                                  f"OpenMP {nproc} threads, gcc -O3, {dt:.1f} s",
+                        "gpu_image0_equals_cpu": bool(np.array_equal(outs[3], gpu_latent0) and np.array_equal(outs[7], gpu_out0))}
+    return res
 
 
 def main():
@@ -71,7 +106,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from simple_image_compression_network_amd import api
+    from simple_image_compression_network_amd import api, codec
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -111,48 +146,91 @@ def main():
     def step():
         net.forward(x, out, latent)
 
+    def timed(fn, steps):
+        """barrier + synchronize on both sides, MAX over ranks."""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     net.profile(True)
     net.layer_ms(reset=True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = timed(step, args.steps)
     layer_ms, launches = net.layer_ms(reset=True)
     net.profile(False)
 
-    # bookkeeping collective only: one checksum per rank so rank 0 can report that every shard ran
-    chk = torch.tensor([int(out.view(-1)[:: 65537].to(torch.int64).sum().item())], dtype=torch.int64, device=cdev)
+    # ---- the TIMED outputs against the committed oracle hashes ------------------------------------
+    out_h, lat_h = out.cpu().numpy(), latent.cpu().numpy()
+    golden_path = ROOT / "tests" / "golden" / "bench_4k_hashes.json"
+    golden = json.loads(golden_path.read_text()) if golden_path.exists() else {}
+    verdict = 1   # 1 = all equal, 0 = a mismatch, -1 = no golden entry for some image (or a non-default size)
+    for i in range(B):
+        g = golden.get(str(rank * B + i)) if (W, H) == (3840, 2160) else None
+        if g is None:
+            verdict = min(verdict, -1) if verdict != 0 else 0
+            continue
+        if [hashlib.sha256(lat_h[i].tobytes()).hexdigest(), hashlib.sha256(out_h[i].tobytes()).hexdigest()] != g:
+            verdict = 0
+    # bookkeeping collectives only: verdict + one checksum per rank, so rank 0 can show every shard ran
+    mine = torch.tensor([verdict, zlib.adler32(out_h.reshape(-1)) & 0xFFFFFFFF], dtype=torch.int64, device=cdev)
+    gathered = [mine]
     if world > 1:
-        chks = [torch.zeros_like(chk) for _ in range(world)]
-        dist.all_gather(chks, chk)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+    verdicts = [int(g[0].item()) for g in gathered]
+    rank_checksums = [int(g[1].item()) for g in gathered]
+
+    # ---- secondary: the same batch through the entropy coder ---------------------------------------
+    with_coder = None
+    if not args.no_coder:
+        lat2 = torch.empty_like(latent)
+        state = {}
+
+        def coder_step():
+            net.analysis(x, latent)
+            slots, sizes = codec.encode_latents(latent, W, H)
+            back, _ = codec.decode_latents(slots, sizes)
+            state["bytes"], state["back"] = sum(sizes), back
+            net.synthesis(back, out)
+
+        coder_step()
+        csteps = max(2, args.steps // 2)
+        cdt = timed(coder_step, csteps)
+        ok = bool(torch.equal(state["back"], latent)) and (zlib.adler32(out.cpu().numpy().reshape(-1)) & 0xFFFFFFFF) == rank_checksums[rank]
+        with_coder = {"value": round(world * B * W * H * csteps / cdt / 1e6, 2), "unit": "Mpixels/s",
+                      "ms_per_step": round(cdt / csteps * 1e3, 3), "steps": csteps,
+                      "bits_per_pixel": round(8.0 * state["bytes"] / (B * W * H), 4), "round_trip_exact": ok,
+                      "path": "analysis (L0-L3) -> sicn_codec_encode_batch (rANS-W) -> sicn_codec_decode_batch -> synthesis (L4-L7)",
+                      "note": "the coder is this project's own (the reference has none); parity unpinned"}
+        del lat2
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
+    import ctypes
     px_per_step = world * B * W * H
     value = px_per_step * args.steps / dt / 1e6
     # ---- roofline of the dominant kernel (largest share of device time) ----------------------
     avg_ms = [m / max(c, 1) for m, c in zip(layer_ms, launches)]
-    names = [api._lib.lib().sicn_kernel_for(__import__("ctypes").byref(d.to_c())).decode() for d in net.descs]
+    names = [api._lib.lib().sicn_kernel_for(ctypes.byref(d.to_c())).decode() for d in net.descs]
     dom = int(np.argmax(avg_ms))
     d = net.descs[dom]
     ops = 2.0 * d.algorithmic_macs * B                     # algorithmic int8 ops per launch (zero-skipped)
-    byts = float(B) * (np.prod(d.in_shape) + np.prod(d.out_shape))   # activation bytes per launch
+    byts = float(B) * (np.prod(d.in_shape) + np.prod(d.out_shape))   # algorithmic activation bytes per launch
     layers = []
     for l, dd in enumerate(net.descs):
         o = 2.0 * dd.algorithmic_macs * B
@@ -160,34 +238,49 @@ def main():
         s = avg_ms[l] * 1e-3
         layers.append({"layer": l, "kernel": names[l], "ms": round(avg_ms[l], 4),
                        "TOPs": round(o / s / 1e12, 2), "GBs": round(by / s / 1e9, 1)})
-    traffic = None
-    pmc = ROOT / "profiles" / "r01_pmc_summary.json"
-    if pmc.exists():
+    # HBM traffic of the dominant kernel: PMC counters cannot be collected inside this run; the figure comes from the
+    # newest profiles/*_pmc_summary.json and only if it was measured on exactly these kernel sources
+    traffic, traffic_source = None, None
+    fp = kernel_source_fingerprint()
+    for pmc in sorted((ROOT / "profiles").glob("r*_pmc_summary.json"), reverse=True):
         try:
-            traffic = json.loads(pmc.read_text()).get("dominant_kernel_hbm_bytes_per_launch")
+            j = json.loads(pmc.read_text())
         except Exception:
-            traffic = None
+            continue
+        if j.get("kernel_source_fingerprint") == fp and j.get("dominant_layer") == dom and (W, H, B) == (3840, 2160, 8):
+            traffic = j.get("dominant_kernel_hbm_bytes_per_launch")
+            traffic_source = f"profiles/{pmc.name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, same kernel sources {fp})"
+            break
+    if traffic is None:
+        traffic_source = f"no PMC summary for kernel sources {fp}: rerun profiles/collect_pmc.sh"
     if names[dom].startswith("mfma"):
         roof = {"bound": "mfma", "achieved": round(ops / (avg_ms[dom] * 1e-3) / 1e12, 2), "peak": PEAK_INT8_TOPS,
                 "unit": "TFLOP/s", "frac": round(ops / (avg_ms[dom] * 1e-3) / 1e12 / PEAK_INT8_TOPS, 4)}
     else:
         roof = {"bound": "hbm", "achieved": round(byts / (avg_ms[dom] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
                 "unit": "GB/s", "frac": round(byts / (avg_ms[dom] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-    roof.update({"traffic": traffic, "kernel": f"layer {dom} ({names[dom]})", "avg_launch_ms": round(avg_ms[dom], 4),
+    roof.update({"traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": int(byts),
+                 "kernel": f"layer {dom} ({names[dom]})", "avg_launch_ms": round(avg_ms[dom], 4),
                  "note": "int8 MAC = 2 ops, counted in the TFLOP/s unit; algorithmic (zero-skipped) work"})
-
+    net_ops = sum(2.0 * dd.algorithmic_macs for dd in net.descs) * B
     res = {
         "metric": "Mpixels/s encode+decode (4K RGB)", "value": round(value, 2), "unit": "Mpixels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
         "data": "synthetic", "config": {"workload": f"{B} x {W}x{H} RGB uint8 images per GPU, eight_layers_net (PARAM weights), "
-                                                    f"BASELINE.json configs[3] shard", "images_per_gpu": B,
-                                        "global_images": world * B, "parallelism": f"image-sharded x{world}"},
+                                                    f"BASELINE.json configs[3] shard; transform only (the reference has no coder)",
+                                        "images_per_gpu": B, "global_images": world * B, "parallelism": f"image-sharded x{world}"},
+        "output_bit_exact": (None if any(v < 0 for v in verdicts) and all(v != 0 for v in verdicts) else all(v == 1 for v in verdicts)),
+        "output_check": "sha256 of every latent and reconstruction of the timed run vs tests/golden/bench_4k_hashes.json (oracle direct form)",
+        "rank_checksums": rank_checksums,
         "roofline": roof, "layers": layers,
         "device_ms_sum_per_step": round(sum(avg_ms), 3),
+        "whole_net_mfma_frac": round(net_ops / (dt / args.steps) / 1e12 / PEAK_INT8_TOPS, 4),
     }
+    if with_coder is not None:
+        res["with_coder"] = with_coder
     if world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(host[0], args.cpu_sample)
+        res["cpu_baseline"] = cpu_baseline(host[0], args.cpu_sample, lat_h[0], out_h[0])
     print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -32,8 +32,12 @@
  * owned by the caller; the library never frees caller memory.  Entry points that take a
  * `hip_stream` only enqueue work on that hipStream_t (NULL = default stream) and perform no
  * allocation or synchronisation, so they can be captured into a hipGraph.  Handles are immutable
- * after creation; concurrent launches on different streams are allowed provided each uses its own
- * workspace.
+ * after creation; concurrent launches on different streams (and from different host threads) are
+ * allowed provided each uses its own workspace.  The library keeps NO mutable process-wide state:
+ * kernel-selection knobs travel in a `sicn_options` value (per call / per net); the SICN_* environment
+ * variables are read exactly once, when the library is loaded, into the defaults `sicn_options_init`
+ * hands out.  The only state a launch touches in a handle is the optional profiling ring of a net,
+ * whose slots are reserved with an atomic counter.
  *
  * Size limits of the specialised kernels (SICN_EINVAL beyond them): one image's input and output
  * < 2 GiB per layer (31-bit offsets inside an image: loads and stores go through buffer descriptors
@@ -79,6 +83,20 @@ typedef struct sicn_layer_desc {
     int32_t transposed; /* 0: conv2d<> ; 1: deconv522<>                                         */
 } sicn_layer_desc;
 
+/* Kernel-selection knobs (tests, A/B experiments; the defaults are the product).  Plain data, copied by
+ * every function that takes it.  Always start from sicn_options_init(). */
+typedef struct sicn_options {
+    int32_t struct_bytes;    /* sizeof(sicn_options) of the caller's build                          */
+    int32_t force_generic;   /* 1: the shape-agnostic kernel (k_generic) for every layer            */
+    int32_t mfma_shape;      /* 0 / 16: v_mfma_i32_16x16x64_i8 kernels; 32: the 32x32x32 kernels    */
+    int32_t tile_x;          /* 0: by layer shape and grid size; 16 / 32: force that M-tile width   */
+    int32_t strip_chunks;    /* 0: automatic; n: cut the vertical strips of the RGB layers into n   */
+    int32_t no_phase_layout; /* 0: default; 1: never use the PHASE layout; 2: not towards layer 7   */
+    int32_t split_n;         /* 0: automatic; 1: never split; 2, 3, 4: output-channel split of the  */
+                             /*    MFMA layers (grids smaller than the chip)                        */
+    int32_t reserved[9];
+} sicn_options;
+
 typedef struct sicn_weights sicn_weights; /* one layer's weights+bias, resident on the device  */
 typedef struct sicn_net sicn_net;         /* a chain of layers (the 8-layer net, or any chain) */
 
@@ -86,6 +104,10 @@ typedef struct sicn_net sicn_net;         /* a chain of layers (the 8-layer net,
 int sicn_version(void);                  /* 1000*major + minor                                 */
 const char *sicn_strerror(int code);
 int sicn_validate_desc(const sicn_layer_desc *desc); /* pure host check, no GPU needed         */
+/* Fills *opt with the library defaults (= all zero, overridden by the SICN_MFMA_SHAPE, SICN_TILE_X,
+ * SICN_STRIP_CHUNKS, SICN_NO_PHASE_LAYOUT, SICN_SPLIT_N, SICN_FORCE_GENERIC environment variables as
+ * they were when the library was loaded). */
+void sicn_options_init(sicn_options *opt);
 
 /* Weights ---------------------------------------------------------------------------------- */
 /* Ingests the reference wire format verbatim.  `m_weights` = HOST array [PE][W_TILES] of words
@@ -104,17 +126,23 @@ int sicn_conv2d(const sicn_layer_desc *desc, const sicn_weights *w, const uint8_
                 uint8_t *out_nhwc, int n_images, void *hip_stream);
 int sicn_deconv522(const sicn_layer_desc *desc, const sicn_weights *w, const uint8_t *in_nhwc,
                    uint8_t *out_nhwc, int n_images, void *hip_stream);
-/* Name of the kernel family that will serve `desc` ("l0_rgb", "mfma_conv", "mfma_deconv",
- * "l7_rgb", "generic"); static string. */
+/* The same with explicit options (NULL = defaults). */
+int sicn_conv2d_opt(const sicn_layer_desc *desc, const sicn_weights *w, const uint8_t *in_nhwc,
+                    uint8_t *out_nhwc, int n_images, const sicn_options *opt, void *hip_stream);
+int sicn_deconv522_opt(const sicn_layer_desc *desc, const sicn_weights *w, const uint8_t *in_nhwc,
+                       uint8_t *out_nhwc, int n_images, const sicn_options *opt, void *hip_stream);
+/* Name of the kernel family that will serve `desc` under the default options ("l0_rgb", "mfma_conv",
+ * "mfma_deconv", "l7_rgb", "generic"); static string. */
 const char *sicn_kernel_for(const sicn_layer_desc *desc);
-/* Force the shape-agnostic kernel for every layer (testing aid; default 0). Process-wide. */
-void sicn_set_force_generic(int on);
 
 /* Layer chains ----------------------------------------------------------------------------- */
 /* descs[i+1] input dims/channels must equal descs[i] output dims/channels.  The net keeps
  * references to `weights` (caller keeps them alive). */
 int sicn_net_create(const sicn_layer_desc *descs, sicn_weights *const *weights, int n_layers,
                     sicn_net **out);
+/* The same with explicit options, fixed for the life of the net (NULL = defaults). */
+int sicn_net_create_opt(const sicn_layer_desc *descs, sicn_weights *const *weights, int n_layers,
+                        const sicn_options *opt, sicn_net **out);
 void sicn_net_free(sicn_net *net);
 /* Bytes of DEVICE scratch `sicn_net_forward` needs for a batch of n_images. */
 size_t sicn_net_workspace_bytes(const sicn_net *net, int n_images);
@@ -131,7 +159,10 @@ int sicn_eight_layers_net(const sicn_net *net, const uint8_t *in, uint8_t *out,
 /* Per-layer device timing (measurement aid) ------------------------------------------------ */
 /* When enabled, sicn_net_forward brackets every layer launch with hipEvents on the launch stream.
  * sicn_net_layer_ms synchronises on the last recorded events and returns, per layer, the SUM of
- * milliseconds and the number of launches since the last reset. */
+ * milliseconds and the number of launches since the last reset.  Forward calls on several streams
+ * may record concurrently (slots are reserved atomically; when the ring of 8192 slots is full, further
+ * launches are simply not timed).  sicn_net_profile / sicn_net_layer_ms themselves must not run
+ * concurrently with forward calls on the same net. */
 int sicn_net_profile(sicn_net *net, int enable);
 int sicn_net_layer_ms(sicn_net *net, int reset, float *ms_sum /*[n_layers]*/,
                       int *launches /*[n_layers]*/);

@@ -79,6 +79,10 @@ int sicn_codec_decode_batch(const uint8_t *containers, size_t slot_bytes, const 
                             uint8_t *latents, size_t latent_stride, sicn_codec_info *infos_or_null, void *workspace,
                             size_t workspace_bytes, void *hip_stream);
 
+/* Self-test (host arithmetic only, no GPU): checks the rANS-W encoder's reciprocal divide against x / f for
+ * f in [f_begin, f_end) over the states the encoder can hold. Returns the number of wrong results (0 = pass). */
+long long sicn_codec_selftest_div(uint32_t f_begin, uint32_t f_end, unsigned long long *n_checked);
+
 #ifdef __cplusplus
 }
 #endif

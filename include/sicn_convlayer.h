@@ -72,6 +72,13 @@ void sicn_convlayer_params_free(sicn_convlayer_params *p);
 int sicn_conv_layer_batch(const sicn_convlayer_desc *desc, const sicn_convlayer_params *params, const uint8_t *in,
                           void *out, int reps, void *hip_stream);
 
+/* The same with the kernel chosen by the caller (tests compare the two): AUTO = the implicit-GEMM MFMA kernel
+ * when the shape allows it, DIRECT = always the one-thread-per-output-lane kernel. */
+#define SICN_CONVLAYER_KERNEL_AUTO 0
+#define SICN_CONVLAYER_KERNEL_DIRECT 1
+int sicn_conv_layer_batch_kernel(const sicn_convlayer_desc *desc, const sicn_convlayer_params *params, const uint8_t *in,
+                                 void *out, int reps, int kernel, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,8 +13,27 @@ from .config import CLayerDesc
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("SICN_LIB", _PKG / "libsicn.so"))
 
-# every symbol include/sicn.h declares: (restype, argtypes)
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+
+
+class COptions(ctypes.Structure):
+    """ctypes image of `sicn_options` (include/sicn.h): kernel-selection knobs, passed by value per call / per net."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("struct_bytes", "force_generic", "mfma_shape", "tile_x", "strip_chunks",
+                                              "no_phase_layout", "split_n")] + [("reserved", ctypes.c_int32 * 9)]
+
+
+def make_options(**kw) -> "COptions":
+    """Library defaults (sicn_options_init) with the given fields replaced, e.g. make_options(tile_x=16)."""
+    o = COptions()
+    lib().sicn_options_init(ctypes.byref(o))
+    for k, v in kw.items():
+        if k not in dict(COptions._fields_) or k in ("struct_bytes", "reserved"):
+            raise AttributeError(f"sicn_options has no field {k}")
+        setattr(o, k, int(v))
+    return o
+
+
+# every symbol include/sicn.h declares: (restype, argtypes)
 _descp = ctypes.POINTER(CLayerDesc)
 ABI = {
     "sicn_version": (_i, []),
@@ -25,7 +44,10 @@ ABI = {
     "sicn_conv2d": (_i, [_descp, _vp, _vp, _vp, _i, _vp]),
     "sicn_deconv522": (_i, [_descp, _vp, _vp, _vp, _i, _vp]),
     "sicn_kernel_for": (ctypes.c_char_p, [_descp]),
-    "sicn_set_force_generic": (None, [_i]),
+    "sicn_options_init": (None, [ctypes.POINTER(COptions)]),
+    "sicn_conv2d_opt": (_i, [_descp, _vp, _vp, _vp, _i, ctypes.POINTER(COptions), _vp]),
+    "sicn_deconv522_opt": (_i, [_descp, _vp, _vp, _vp, _i, ctypes.POINTER(COptions), _vp]),
+    "sicn_net_create_opt": (_i, [_descp, ctypes.POINTER(_vp), _i, ctypes.POINTER(COptions), ctypes.POINTER(_vp)]),
     "sicn_net_create": (_i, [_descp, ctypes.POINTER(_vp), _i, ctypes.POINTER(_vp)]),
     "sicn_net_free": (None, [_vp]),
     "sicn_net_workspace_bytes": (_sz, [_vp, _i]),
@@ -56,6 +78,7 @@ CONVLAYER_ABI = {
     "sicn_convlayer_params_create": (_i, [_cldp, _vp, _i, _vp, ctypes.POINTER(_vp)]),
     "sicn_convlayer_params_free": (None, [_vp]),
     "sicn_conv_layer_batch": (_i, [_cldp, _vp, _vp, _vp, _i, _vp]),
+    "sicn_conv_layer_batch_kernel": (_i, [_cldp, _vp, _vp, _vp, _i, _i, _vp]),
 }
 
 _u32 = ctypes.c_uint32
@@ -69,6 +92,7 @@ CODEC_ABI = {
     "sicn_codec_batch_workspace_bytes": (_sz, [_i, _u32, _u32]),
     "sicn_codec_encode_batch": (_i, [_i, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _sz, ctypes.POINTER(_sz), _vp, _sz, _vp]),
     "sicn_codec_decode_batch": (_i, [_vp, _sz, ctypes.POINTER(_sz), _u32, _vp, _sz, ctypes.POINTER(CodecInfo), _vp, _sz, _vp]),
+    "sicn_codec_selftest_div": (ctypes.c_longlong, [_u32, _u32, ctypes.POINTER(ctypes.c_ulonglong)]),
 }
 
 _lib = None

@@ -97,7 +97,16 @@ def _as_device(desc, weights, bias) -> DeviceWeights:
     return weights if isinstance(weights, DeviceWeights) else DeviceWeights(desc, weights, bias)
 
 
-def _run(fn_name, desc, weights, bias, in_, out, numReps, stream):
+def _opt_ptr(options):
+    """options: None (library defaults), a dict of sicn_options fields, or a _lib.COptions."""
+    if options is None:
+        return None
+    if isinstance(options, dict):
+        options = _lib.make_options(**options)
+    return ctypes.byref(options)
+
+
+def _run(fn_name, desc, weights, bias, in_, out, numReps, stream, options=None):
     import torch
     L = _lib.lib()
     desc.validate()
@@ -107,19 +116,21 @@ def _run(fn_name, desc, weights, bias, in_, out, numReps, stream):
         out = torch.empty((numReps,) + desc.out_shape, dtype=torch.uint8, device=in_.device)
     _check_tensor(out, (numReps,) + desc.out_shape, "out")
     cd = desc.to_c()
-    _lib.check(getattr(L, fn_name)(ctypes.byref(cd), dw.handle, ctypes.c_void_p(in_.data_ptr()),
-                                   ctypes.c_void_p(out.data_ptr()), numReps, _stream_ptr(stream)), fn_name)
+    _lib.check(getattr(L, fn_name + "_opt")(ctypes.byref(cd), dw.handle, ctypes.c_void_p(in_.data_ptr()),
+                                            ctypes.c_void_p(out.data_ptr()), numReps, _opt_ptr(options),
+                                            _stream_ptr(stream)), fn_name)
     return out
 
 
-def conv2d(desc: LayerDesc, weights, bias, in_, out=None, numReps: int = 1, stream=None):
-    """`conv2d<...>(weights, bias, in, out, numReps)` — conv_nonsquare_top.cpp:198-280."""
-    return _run("sicn_conv2d", desc, weights, bias, in_, out, numReps, stream)
+def conv2d(desc: LayerDesc, weights, bias, in_, out=None, numReps: int = 1, stream=None, options=None):
+    """`conv2d<...>(weights, bias, in, out, numReps)` — conv_nonsquare_top.cpp:198-280.
+    `options`: sicn_options fields as a dict (kernel-selection knobs for tests / experiments)."""
+    return _run("sicn_conv2d", desc, weights, bias, in_, out, numReps, stream, options)
 
 
-def deconv522(desc: LayerDesc, weights, bias, in_, out=None, numReps: int = 1, stream=None):
+def deconv522(desc: LayerDesc, weights, bias, in_, out=None, numReps: int = 1, stream=None, options=None):
     """`deconv522<...>(weights, bias, in, out, numReps)` — conv_nonsquare_top.cpp:71-195."""
-    return _run("sicn_deconv522", desc, weights, bias, in_, out, numReps, stream)
+    return _run("sicn_deconv522", desc, weights, bias, in_, out, numReps, stream, options)
 
 
 # ---- the PARAM:: tables (memdata_nonsquare.h) -------------------------------------------------
@@ -157,7 +168,8 @@ class EightLayersNet:
     current stream and returns (reconstruction, latent)."""
 
     def __init__(self, width: int = 768, height: int = 512, params=None, device=None,
-                 descs: Optional[Sequence[LayerDesc]] = None, shared_weights: Optional[Sequence[DeviceWeights]] = None):
+                 descs: Optional[Sequence[LayerDesc]] = None, shared_weights: Optional[Sequence[DeviceWeights]] = None,
+                 options=None):
         import torch
         L = _lib.lib()
         self.descs: List[LayerDesc] = list(descs) if descs is not None else eight_layer_descs(width, height)
@@ -172,7 +184,7 @@ class EightLayersNet:
         cdescs = (CLayerDesc * n)(*[d.to_c() for d in self.descs])
         handles = (ctypes.c_void_p * n)(*[w.handle for w in self.weights])
         self._h = ctypes.c_void_p()
-        _lib.check(L.sicn_net_create(cdescs, handles, n, ctypes.byref(self._h)), "sicn_net_create")
+        _lib.check(L.sicn_net_create_opt(cdescs, handles, n, _opt_ptr(options), ctypes.byref(self._h)), "sicn_net_create_opt")
         self._ws = None
         self._ws_images = 0
 
@@ -235,13 +247,23 @@ class EightLayersNet:
                 gc.enable()
         return graph
 
-    def run_layers(self, first: int, last: int, in_, tap_layer: int = -1, stream=None):
+    def analysis(self, in_, latent=None, stream=None):
+        """Encoder half: layers 0..3, image batch -> latent (conv_3_out, conv_nonsquare_top.cpp:322-325)."""
+        return self.run_layers(0, 3, in_, out=latent, stream=stream)[0]
+
+    def synthesis(self, latent, out=None, stream=None):
+        """Decoder half: layers 4..7, latent -> reconstruction."""
+        return self.run_layers(4, len(self.descs) - 1, latent, out=out, stream=stream)[0]
+
+    def run_layers(self, first: int, last: int, in_, tap_layer: int = -1, stream=None, out=None):
         """Layers [first, last] of the chain (sicn_net_forward); returns (out, tap or None)."""
         import torch
         L = _lib.lib()
         n = in_.shape[0]
         _check_tensor(in_, (n,) + self.descs[first].in_shape, "in")
-        out = torch.empty((n,) + self.descs[last].out_shape, dtype=torch.uint8, device=in_.device)
+        if out is None:
+            out = torch.empty((n,) + self.descs[last].out_shape, dtype=torch.uint8, device=in_.device)
+        _check_tensor(out, (n,) + self.descs[last].out_shape, "out")
         tap = None
         tap_ptr = ctypes.c_void_p(0)
         if tap_layer >= 0:

@@ -67,9 +67,11 @@ class ConvLayerDesc:
                                    ACT_VAL=int(activation.ACT_VAL) if th else 0)
 
 
-def ConvLayer_Batch(desc: ConvLayerDesc, in_, out, weights: FixedPointWeights, activation, reps: int = 1, stream=None):
+def ConvLayer_Batch(desc: ConvLayerDesc, in_, out, weights: FixedPointWeights, activation, reps: int = 1, stream=None,
+                    kernel: int = 0):
     """in_: CUDA uint8 [reps][IFM_DIM][IFM_DIM][IFM_CH]; out: CUDA tensor [reps][OFM_DIM][OFM_DIM][OFM_CH] of dtype
-    uint8 / int16 / int32 matching OUT_BIT, or None to allocate.  Returns `out`."""
+    uint8 / int16 / int32 matching OUT_BIT, or None to allocate.  Returns `out`.
+    kernel: 0 = automatic (MFMA kernel when the shape allows), 1 = the direct kernel (tests compare the two)."""
     import torch
     L = _lib.lib()
     cd = desc.to_c(activation)
@@ -96,8 +98,9 @@ def ConvLayer_Batch(desc: ConvLayerDesc, in_, out, weights: FixedPointWeights, a
                                               thr.ctypes.data_as(ctypes.c_void_p) if thr is not None else None,
                                               ctypes.byref(h)), "sicn_convlayer_params_create")
     try:
-        _lib.check(L.sicn_conv_layer_batch(ctypes.byref(cd), h, ctypes.c_void_p(in_.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                                           reps, _stream_ptr(stream)), "sicn_conv_layer_batch")
+        _lib.check(L.sicn_conv_layer_batch_kernel(ctypes.byref(cd), h, ctypes.c_void_p(in_.data_ptr()),
+                                                  ctypes.c_void_p(out.data_ptr()), reps, int(kernel), _stream_ptr(stream)),
+                   "sicn_conv_layer_batch_kernel")
         torch.cuda.current_stream().synchronize()     # the parameter handle is freed below
     finally:
         L.sicn_convlayer_params_free(h)

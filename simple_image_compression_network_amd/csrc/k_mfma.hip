@@ -429,11 +429,7 @@ SICN_INST(4, 6, false, 0)
 SICN_INST(4, 6, false, 1)
 #undef SICN_INST
 
-static int mfma_variant()
-{
-    const char *x = getenv("SICN_MFMA_VARIANT");  // read per launch: in-process A/B (tools/ab_variants.py)
-    return x ? atoi(x) : 0;
-}
+static int mfma_variant() { return debug_env().mfma_variant; }   // environment read once at load (sicn_abi.hip)
 
 template <int NQ, int NTJ, bool DECONV, int VARIANT>
 static hipError_t launch_var(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
@@ -444,14 +440,14 @@ static hipError_t launch_var(const LayerGeom &g, const sicn_weights &w, const ui
     const int MW = DECONV ? g.IW : g.OW, MH = DECONV ? g.IH : g.OH;
     const int tiles_x = (MW + TILE_X - 1) / TILE_X, tiles_y = (MH + TILE_Y - 1) / TILE_Y;
     size_t lds = (size_t)NSUB * SUB_ALLOC + (size_t)RING * NTJ * 32 * KSTEP;
-    if (const char *x = getenv("SICN_DEBUG_EXTRA_LDS")) lds += (size_t)atoi(x);  // occupancy experiments only
+    lds += (size_t)debug_env().extra_lds;  // occupancy experiments only (SICN_DEBUG_EXTRA_LDS at load time)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mfma_t<NQ, NTJ, DECONV, MINW, VARIANT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)(tiles_x * tiles_y), 1, (unsigned)n_images);
     hipLaunchKernelGGL((k_mfma_t<NQ, NTJ, DECONV, MINW, VARIANT>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma,
                        w.d_bias, g.IW, g.IH, g.OW, g.OH, MW, MH, tiles_x, in_layout, out_layout,
-                       getenv("SICN_DEBUG_KERNEL") ? atoi(getenv("SICN_DEBUG_KERNEL")) : 0);
+                       debug_env().debug_kernel);
     return hipGetLastError();
 }
 

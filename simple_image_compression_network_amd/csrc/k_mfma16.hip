@@ -380,33 +380,32 @@ static hipError_t launch16_tx(const LayerGeom &g, const sicn_weights &w, const u
 }
 
 // Tile width: 8 x 32 positions by default; 8 x 16 where the wide tile allows only one workgroup per CU
-// (the 192-channel layers) or leaves most of the chip without a tile (small images).  SICN_TILE_X=16|32
-// forces one (experiments, tests; read per launch).
+// (the 192-channel layers) or leaves most of the chip without a tile (small images).  sicn_options.tile_x = 16|32
+// forces one (experiments, tests).
 template <int NQ, int NT16, bool DECONV>
 static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
-                           hipStream_t stream, int in_layout, int out_layout)
+                           hipStream_t stream, int in_layout, int out_layout, const sicn_options &o)
 {
     const int MW = DECONV ? g.IW : g.OW, MH = DECONV ? g.IH : g.OH;
     const long tiles32 = (long)((MW + 31) / 32) * ((MH + TILE_Y - 1) / TILE_Y) * n_images;
     bool narrow = minw16(NQ, NT16, 32) == 1 || tiles32 < 2 * 256;
-    const char *e = getenv("SICN_TILE_X");
-    if (e && e[0] == '1') narrow = true;
-    if (e && e[0] == '3') narrow = false;
+    if (o.tile_x == 16) narrow = true;
+    if (o.tile_x == 32) narrow = false;
     return narrow ? launch16_tx<NQ, NT16, DECONV, 16>(g, w, in, out, n_images, stream, in_layout, out_layout)
                   : launch16_tx<NQ, NT16, DECONV, 32>(g, w, in, out, n_images, stream, in_layout, out_layout);
 }
 
 hipError_t launch_mfma16(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
-                         hipStream_t stream, int in_layout, int out_layout)
+                         hipStream_t stream, int in_layout, int out_layout, const sicn_options &o)
 {
     if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB) return hipErrorInvalidValue;          // 31-bit patch offsets
     if ((size_t)g.OH * g.OW * g.COUT >= (size_t)OOB) return hipErrorInvalidValue;         // buffer-descriptor stores
     if (g.transposed) {
-        if (g.CIN == 128 && g.COUT == 128) return launch16<4, 8, true>(g, w, in, out, n_images, stream, in_layout, out_layout);
-        if (g.CIN == 192 && g.COUT == 128) return launch16<6, 8, true>(g, w, in, out, n_images, stream, in_layout, out_layout);
+        if (g.CIN == 128 && g.COUT == 128) return launch16<4, 8, true>(g, w, in, out, n_images, stream, in_layout, out_layout, o);
+        if (g.CIN == 192 && g.COUT == 128) return launch16<6, 8, true>(g, w, in, out, n_images, stream, in_layout, out_layout, o);
     } else {
-        if (g.CIN == 128 && g.COUT == 128) return launch16<4, 8, false>(g, w, in, out, n_images, stream, in_layout, out_layout);
-        if (g.CIN == 128 && g.COUT == 192) return launch16<4, 12, false>(g, w, in, out, n_images, stream, in_layout, out_layout);
+        if (g.CIN == 128 && g.COUT == 128) return launch16<4, 8, false>(g, w, in, out, n_images, stream, in_layout, out_layout, o);
+        if (g.CIN == 128 && g.COUT == 192) return launch16<4, 12, false>(g, w, in, out, n_images, stream, in_layout, out_layout, o);
     }
     return hipErrorInvalidValue;
 }

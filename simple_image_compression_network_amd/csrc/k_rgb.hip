@@ -192,14 +192,8 @@ __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, u
     }
 }
 
-// Test hook: SICN_STRIP_CHUNKS=n forces the number of vertical chunks a strip is cut into (the
-// default heuristic gives small images one step per workgroup, which never exercises the rolling
-// window); read per launch.
-static int strip_chunks_override()
-{
-    const char *e = getenv("SICN_STRIP_CHUNKS");
-    return (e && *e) ? atoi(e) : 0;
-}
+// Test hook: sicn_options.strip_chunks = n forces the number of vertical chunks a strip is cut into (the
+// default heuristic gives small images one step per workgroup, which never exercises the rolling window).
 
 size_t l0_bytes(int cout) { return (size_t)5 * cout * KSTEP; }
 
@@ -222,13 +216,13 @@ void pack_l0(const int8_t *w_okc, int cout, int8_t *dst)
 }
 
 hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream, int out_layout)
+                     int n_images, hipStream_t stream, int out_layout, const sicn_options &o)
 {
     const int tiles_x = (g.OW + TILE_X - 1) / TILE_X, tiles_y = (g.OH + L0_TY - 1) / L0_TY;
     // runs of at most L0_CHUNK tiles (the LDS holds a run's pixels), evened out; the test hook can only shorten them
     int y_chunks = (tiles_y + L0_CHUNK - 1) / L0_CHUNK;
     int want = (1024 + tiles_x * n_images - 1) / (tiles_x * n_images);   // small images: shorter runs, enough workgroups
-    const int forced = strip_chunks_override();
+    const int forced = o.strip_chunks;
     if (forced > 0) want = forced;
     if (want > y_chunks) y_chunks = want > tiles_y ? tiles_y : want;
     const int ty_per = (tiles_y + y_chunks - 1) / y_chunks;
@@ -485,13 +479,13 @@ void pack_l7(const int8_t *w_okc, int cin, int8_t *dst)
 }
 
 hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream, int in_layout)
+                     int n_images, hipStream_t stream, int in_layout, const sicn_options &o)
 {
     if (g.CIN != 128 || g.COUT != 3) return hipErrorInvalidValue;
     if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB) return hipErrorInvalidValue;
     if ((size_t)g.OH * g.OW * 3 >= (size_t)OOB) return hipErrorInvalidValue;   // buffer-descriptor stores
     const int tiles_x = (g.IW + TILE_X - 1) / TILE_X, steps_y = (g.IH + L7_ROWS - 1) / L7_ROWS;
-    int y_chunks = strip_chunks_override();
+    int y_chunks = o.strip_chunks;
     if (y_chunks <= 0) y_chunks = (6144 + tiles_x * n_images - 1) / (tiles_x * n_images);
     y_chunks = y_chunks < 1 ? 1 : (y_chunks > steps_y ? steps_y : y_chunks);
     const size_t lds = 2 * L7_REGION + 4 * L7_STAGE + 1024;

@@ -1,7 +1,9 @@
 // libsicn.so — C ABI (include/sicn.h): descriptor validation, weight ingestion from the
 // reference's FixedPointWeights tile format, kernel dispatch, layer chains with caller-provided
 // workspace, per-layer hipEvent timing.  Host code only; kernels live in k_*.hip.
+#include <atomic>
 #include <cstdlib>
+#include <cstring>
 #include <new>
 #include <vector>
 
@@ -9,7 +11,60 @@
 
 using namespace sicn;
 
-static int g_force_generic = 0;
+// ---- options: no mutable process-wide state. The environment is read exactly once (thread-safe static
+// ---- initialisation at first use, in practice at load) into an immutable default; everything else
+// ---- travels by value in sicn_options.
+namespace sicn {
+static int env_int(const char *name)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? atoi(e) : 0;
+}
+const sicn_options &default_options()
+{
+    static const sicn_options o = [] {
+        sicn_options d;
+        std::memset(&d, 0, sizeof d);
+        d.struct_bytes = (int32_t)sizeof(sicn_options);
+        d.force_generic = env_int("SICN_FORCE_GENERIC") != 0;
+        d.mfma_shape = env_int("SICN_MFMA_SHAPE");
+        d.tile_x = env_int("SICN_TILE_X");
+        d.strip_chunks = env_int("SICN_STRIP_CHUNKS");
+        d.no_phase_layout = env_int("SICN_NO_PHASE_LAYOUT");
+        d.split_n = env_int("SICN_SPLIT_N");
+        return d;
+    }();
+    return o;
+}
+const DebugEnv &debug_env()
+{
+    static const DebugEnv d{env_int("SICN_MFMA_VARIANT"), env_int("SICN_DEBUG_KERNEL"), env_int("SICN_DEBUG_EXTRA_LDS")};
+    return d;
+}
+}  // namespace sicn
+
+// a caller's options -> a validated copy (NULL = defaults; a shorter struct from an older build is zero-extended)
+static int resolve_options(const sicn_options *in, sicn_options *out)
+{
+    *out = default_options();
+    if (!in) return SICN_OK;
+    if (in->struct_bytes < 8 || in->struct_bytes > (int32_t)sizeof(sicn_options)) return SICN_EINVAL;
+    sicn_options o;
+    std::memset(&o, 0, sizeof o);
+    std::memcpy(&o, in, (size_t)in->struct_bytes);
+    o.struct_bytes = (int32_t)sizeof(sicn_options);
+    if (o.mfma_shape != 0 && o.mfma_shape != 16 && o.mfma_shape != 32) return SICN_EINVAL;
+    if (o.tile_x != 0 && o.tile_x != 16 && o.tile_x != 32) return SICN_EINVAL;
+    if (o.strip_chunks < 0 || o.no_phase_layout < 0 || o.no_phase_layout > 2) return SICN_EINVAL;
+    if (o.split_n < 0 || o.split_n > 4) return SICN_EINVAL;
+    *out = o;
+    return SICN_OK;
+}
+
+extern "C" void sicn_options_init(sicn_options *opt)
+{
+    if (opt) *opt = default_options();
+}
 
 extern "C" int sicn_version(void) { return 1000 * 0 + 1; }
 
@@ -55,9 +110,9 @@ extern "C" int sicn_validate_desc(const sicn_layer_desc *d)
 }
 
 namespace sicn {
-KernelKind pick_kernel(const sicn_layer_desc &d)
+KernelKind pick_kernel(const sicn_layer_desc &d, const sicn_options &o)
 {
-    if (g_force_generic) return KK_GENERIC;
+    if (o.force_generic) return KK_GENERIC;
     if (!d.transposed && d.IFM_CH == 3 && d.OFM_CH == 128) return KK_L0_RGB;
     if (d.transposed && d.IFM_CH == 128 && d.OFM_CH == 3) return KK_L7_RGB;
     if (mfma_supported(d.IFM_CH, d.OFM_CH, d.transposed)) return d.transposed ? KK_MFMA_DECONV : KK_MFMA_CONV;
@@ -68,7 +123,7 @@ KernelKind pick_kernel(const sicn_layer_desc &d)
 extern "C" const char *sicn_kernel_for(const sicn_layer_desc *d)
 {
     if (sicn_validate_desc(d)) return "invalid";
-    switch (pick_kernel(*d)) {
+    switch (pick_kernel(*d, default_options())) {
     case KK_L0_RGB: return "l0_rgb";
     case KK_L7_RGB: return "l7_rgb";
     case KK_MFMA_CONV: return "mfma_conv";
@@ -76,8 +131,6 @@ extern "C" const char *sicn_kernel_for(const sicn_layer_desc *d)
     default: return "generic";
     }
 }
-
-extern "C" void sicn_set_force_generic(int on) { g_force_generic = on ? 1 : 0; }
 
 // ---- weights ----------------------------------------------------------------------------------
 static bool upload(const void *host, size_t bytes, int8_t **dev)
@@ -178,22 +231,23 @@ extern "C" int sicn_weights_from_finn_tiles(const sicn_layer_desc *d, const void
 // ---- single layers ------------------------------------------------------------------------------
 // Layout of the tensor between layer `p` (producer) and layer `c` (consumer) of a chain: the best
 // one both kernels implement (k_common.hpp).  0 = NHWC, 1 = GROUP, 2 = PHASE.
-static int link_layout(const sicn_layer_desc &p, const sicn_layer_desc &c)
+static int link_layout(const sicn_layer_desc &p, const sicn_layer_desc &c, const sicn_options &o)
 {
-    const KernelKind kp = pick_kernel(p), kc = pick_kernel(c);
+    const KernelKind kp = pick_kernel(p, o), kc = pick_kernel(c, o);
     const bool w_group = kp == KK_MFMA_CONV || kp == KK_MFMA_DECONV || kp == KK_L0_RGB;
     const bool w_phase = kp == KK_MFMA_DECONV;   // its outputs come one pixel parity at a time
     const bool r_group = kc == KK_MFMA_CONV || kc == KK_MFMA_DECONV || kc == KK_L7_RGB;
     const bool r_phase = kc == KK_MFMA_DECONV || kc == KK_L7_RGB;
-    const char *np = getenv("SICN_NO_PHASE_LAYOUT");   // experiments: "1" = never, "2" = not towards the RGB layer
-    const bool phase_ok = !np || np[0] == '0' || (np[0] == '2' && kc != KK_L7_RGB);
+    // experiments: no_phase_layout 1 = never, 2 = not towards the RGB layer
+    const bool phase_ok = o.no_phase_layout == 0 || (o.no_phase_layout == 2 && kc != KK_L7_RGB);
     if (w_phase && r_phase && phase_ok) return 2;
     if (w_group && r_group) return 1;
     return 0;
 }
 
 static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream, int want_transposed, int in_layout = 0, int out_layout = 0)
+                     int n_images, hipStream_t stream, int want_transposed, const sicn_options &o, int in_layout = 0,
+                     int out_layout = 0)
 {
     int rc = sicn_validate_desc(d);
     if (rc) return rc;
@@ -204,19 +258,16 @@ static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint
     if (n_images > 65535) return SICN_EINVAL;
     const LayerGeom g = geom_of(*d);
     hipError_t e;
-    switch (pick_kernel(*d)) {
-    case KK_L0_RGB: e = launch_l0(g, *w, in, out, n_images, stream, out_layout); break;
-    case KK_L7_RGB: e = launch_l7(g, *w, in, out, n_images, stream, in_layout); break;
+    switch (pick_kernel(*d, o)) {
+    case KK_L0_RGB: e = launch_l0(g, *w, in, out, n_images, stream, out_layout, o); break;
+    case KK_L7_RGB: e = launch_l7(g, *w, in, out, n_images, stream, in_layout, o); break;
     case KK_MFMA_CONV:
-    case KK_MFMA_DECONV: {
-        // MFMA shape: 16x16x64 by default (higher sustained clock, k_mfma16.hip); SICN_MFMA_SHAPE=32 selects
-        // the 32x32x32 kernels of k_mfma.hip (read per launch so both can be compared in one process)
-        const char *shape = getenv("SICN_MFMA_SHAPE");
-        e = (shape && shape[0] == '3')
-                ? launch_mfma(g, *w, in, out, n_images, stream, in_layout, out_layout)
-                : launch_mfma16(g, *w, in, out, n_images, stream, in_layout, out_layout);
+    case KK_MFMA_DECONV:
+        // MFMA shape: 16x16x64 by default (higher sustained clock, k_mfma16.hip); mfma_shape = 32 selects
+        // the 32x32x32 kernels of k_mfma.hip (a second implementation kept under test)
+        e = o.mfma_shape == 32 ? launch_mfma(g, *w, in, out, n_images, stream, in_layout, out_layout)
+                               : launch_mfma16(g, *w, in, out, n_images, stream, in_layout, out_layout, o);
         break;
-    }
     default: e = launch_generic(g, *w, in, out, n_images, stream); break;
     }
     if (e == hipErrorInvalidValue) return SICN_EINVAL;
@@ -226,24 +277,43 @@ static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint
 extern "C" int sicn_conv2d(const sicn_layer_desc *d, const sicn_weights *w, const uint8_t *in, uint8_t *out,
                            int n_images, void *hip_stream)
 {
-    return run_layer(d, w, in, out, n_images, (hipStream_t)hip_stream, 0);
+    return run_layer(d, w, in, out, n_images, (hipStream_t)hip_stream, 0, default_options());
+}
+
+extern "C" int sicn_conv2d_opt(const sicn_layer_desc *d, const sicn_weights *w, const uint8_t *in, uint8_t *out,
+                               int n_images, const sicn_options *opt, void *hip_stream)
+{
+    sicn_options o;
+    int rc = resolve_options(opt, &o);
+    return rc ? rc : run_layer(d, w, in, out, n_images, (hipStream_t)hip_stream, 0, o);
 }
 
 extern "C" int sicn_deconv522(const sicn_layer_desc *d, const sicn_weights *w, const uint8_t *in,
                               uint8_t *out, int n_images, void *hip_stream)
 {
-    return run_layer(d, w, in, out, n_images, (hipStream_t)hip_stream, 1);
+    return run_layer(d, w, in, out, n_images, (hipStream_t)hip_stream, 1, default_options());
+}
+
+extern "C" int sicn_deconv522_opt(const sicn_layer_desc *d, const sicn_weights *w, const uint8_t *in, uint8_t *out,
+                                  int n_images, const sicn_options *opt, void *hip_stream)
+{
+    sicn_options o;
+    int rc = resolve_options(opt, &o);
+    return rc ? rc : run_layer(d, w, in, out, n_images, (hipStream_t)hip_stream, 1, o);
 }
 
 // ---- layer chains ---------------------------------------------------------------------------------
 struct sicn_net {
     std::vector<sicn_layer_desc> descs;
     std::vector<const sicn_weights *> weights;
-    // profiling
-    bool profile = false;
-    static constexpr int EV_RING = 1024;
-    std::vector<hipEvent_t> ev_begin, ev_end;  // [layer * EV_RING + slot]
-    std::vector<int> ev_count;                 // launches recorded per layer since reset
+    sicn_options opt;                          // fixed at creation
+    // profiling: the only state a launch changes.  One flat ring of event pairs; a forward call reserves the
+    // slots of its layers with one atomic fetch_add, so calls on several streams / threads never share a slot.
+    static constexpr int EV_RING = 8192;
+    mutable std::atomic<bool> profile{false};
+    mutable std::atomic<int> ev_next{0};       // slots handed out since the last reset (may run past EV_RING)
+    std::vector<hipEvent_t> ev_begin, ev_end;  // [EV_RING], created by sicn_net_profile
+    mutable std::vector<int> ev_layer;         // [EV_RING] layer recorded in the slot
 };
 
 static size_t out_bytes(const sicn_layer_desc &d) { return (size_t)d.OFM_COL * d.OFM_ROW * d.OFM_CH; }
@@ -253,9 +323,17 @@ static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 extern "C" int sicn_net_create(const sicn_layer_desc *descs, sicn_weights *const *weights, int n_layers,
                                sicn_net **out)
 {
+    return sicn_net_create_opt(descs, weights, n_layers, nullptr, out);
+}
+
+extern "C" int sicn_net_create_opt(const sicn_layer_desc *descs, sicn_weights *const *weights, int n_layers,
+                                   const sicn_options *opt, sicn_net **out)
+{
     if (!out) return SICN_EINVAL;
     *out = nullptr;
     if (!descs || !weights || n_layers <= 0 || n_layers > 64) return SICN_EINVAL;
+    sicn_options o;
+    if (int rc = resolve_options(opt, &o)) return rc;
     for (int i = 0; i < n_layers; i++) {
         int rc = sicn_validate_desc(&descs[i]);
         if (rc) return rc;
@@ -271,7 +349,7 @@ extern "C" int sicn_net_create(const sicn_layer_desc *descs, sicn_weights *const
     try {
         net->descs.assign(descs, descs + n_layers);
         net->weights.assign(weights, weights + n_layers);
-        net->ev_count.assign(n_layers, 0);
+        net->opt = o;
     } catch (const std::bad_alloc &) {
         delete net;
         return SICN_ENOMEM;
@@ -302,11 +380,10 @@ extern "C" size_t sicn_net_workspace_bytes(const sicn_net *net, int n_images)
     return 2 * pingpong_slot_bytes(net, n_images);
 }
 
-extern "C" int sicn_net_forward(const sicn_net *net_c, int first, int last, const uint8_t *in, uint8_t *out,
+extern "C" int sicn_net_forward(const sicn_net *net, int first, int last, const uint8_t *in, uint8_t *out,
                                 int tap_layer, uint8_t *tap_out, int n_images, void *workspace,
                                 size_t workspace_bytes, void *hip_stream)
 {
-    sicn_net *net = const_cast<sicn_net *>(net_c);  // profiling counters only
     if (!net || !in || !out || n_images < 0) return SICN_EINVAL;
     const int n_layers = (int)net->descs.size();
     if (first < 0 || last >= n_layers || first > last) return SICN_EINVAL;
@@ -318,19 +395,27 @@ extern "C" int sicn_net_forward(const sicn_net *net_c, int first, int last, cons
     uint8_t *pp[2] = {(uint8_t *)workspace, (uint8_t *)workspace + slot};
     const uint8_t *cur = in;
     int cur_layout = 0;  // the chain's input is always NHWC
+    // profiling: reserve this call's event slots (one per layer) in one atomic step
+    int slot0 = -1;
+    if (net->profile.load(std::memory_order_acquire)) {
+        const int need = last - first + 1;
+        const int at = net->ev_next.fetch_add(need, std::memory_order_relaxed);
+        if (at + need <= sicn_net::EV_RING) slot0 = at;   // ring full: this call is not timed
+    }
     for (int l = first; l <= last; l++) {
         uint8_t *dst = (l == last) ? out : pp[(l - first) & 1];
         // intermediates nobody outside sees travel in the grouped layout when both neighbours can
-        const int out_layout = (l < last && l != tap_layer) ? link_layout(net->descs[l], net->descs[l + 1]) : 0;
-        const bool prof = net->profile && net->ev_count[l] < sicn_net::EV_RING;
-        if (prof && hipEventRecord(net->ev_begin[(size_t)l * sicn_net::EV_RING + net->ev_count[l]], stream) != hipSuccess)
-            return SICN_ENODEV;
-        int rc = run_layer(&net->descs[l], net->weights[l], cur, dst, n_images, stream, -1, cur_layout, out_layout);
+        const int out_layout = (l < last && l != tap_layer) ? link_layout(net->descs[l], net->descs[l + 1], net->opt) : 0;
+        const int slot = slot0 >= 0 ? slot0 + (l - first) : -1;
+        if (slot >= 0) {
+            net->ev_layer[slot] = -1;   // becomes l once both events are recorded
+            if (hipEventRecord(net->ev_begin[slot], stream) != hipSuccess) return SICN_ENODEV;
+        }
+        int rc = run_layer(&net->descs[l], net->weights[l], cur, dst, n_images, stream, -1, net->opt, cur_layout, out_layout);
         if (rc) return rc;
-        if (prof) {
-            if (hipEventRecord(net->ev_end[(size_t)l * sicn_net::EV_RING + net->ev_count[l]], stream) != hipSuccess)
-                return SICN_ENODEV;
-            net->ev_count[l]++;
+        if (slot >= 0) {
+            if (hipEventRecord(net->ev_end[slot], stream) != hipSuccess) return SICN_ENODEV;
+            net->ev_layer[slot] = l;
         }
         if (l == tap_layer && tap_out != dst) {
             if (hipMemcpyAsync(tap_out, dst, out_bytes(net->descs[l]) * (size_t)n_images, hipMemcpyDeviceToDevice,
@@ -358,38 +443,54 @@ extern "C" int sicn_net_profile(sicn_net *net, int enable)
 {
     if (!net) return SICN_EINVAL;
     if (enable && net->ev_begin.empty()) {
-        const size_t n = net->descs.size() * (size_t)sicn_net::EV_RING;
+        const size_t n = (size_t)sicn_net::EV_RING;
+        std::vector<hipEvent_t> a, b;
         try {
-            net->ev_begin.reserve(n);
-            net->ev_end.reserve(n);
+            a.reserve(n);
+            b.reserve(n);
+            net->ev_layer.assign(n, -1);
         } catch (const std::bad_alloc &) { return SICN_ENOMEM; }
-        for (size_t i = 0; i < n; i++) {
-            hipEvent_t a, b;
-            if (hipEventCreate(&a) != hipSuccess) return SICN_ENODEV;
-            net->ev_begin.push_back(a);
-            if (hipEventCreate(&b) != hipSuccess) return SICN_ENODEV;
-            net->ev_end.push_back(b);
+        bool ok = true;
+        for (size_t i = 0; i < n && ok; i++) {
+            hipEvent_t e;
+            if ((ok = hipEventCreate(&e) == hipSuccess)) a.push_back(e);
+            if (ok && (ok = hipEventCreate(&e) == hipSuccess)) b.push_back(e);
         }
+        if (!ok) {   // all or nothing: a half-made ring would be indexed out of range later
+            for (hipEvent_t e : a) (void)hipEventDestroy(e);
+            for (hipEvent_t e : b) (void)hipEventDestroy(e);
+            return SICN_ENODEV;
+        }
+        net->ev_begin.swap(a);
+        net->ev_end.swap(b);
     }
-    net->profile = enable != 0;
+    net->profile.store(enable != 0, std::memory_order_release);
     return SICN_OK;
 }
 
 extern "C" int sicn_net_layer_ms(sicn_net *net, int reset, float *ms_sum, int *launches)
 {
     if (!net || !ms_sum || !launches) return SICN_EINVAL;
-    for (size_t l = 0; l < net->descs.size(); l++) {
-        float sum = 0.f;
-        for (int k = 0; k < net->ev_count[l]; k++) {
-            const size_t i = l * sicn_net::EV_RING + k;
-            if (hipEventSynchronize(net->ev_end[i]) != hipSuccess) return SICN_ENODEV;
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, net->ev_begin[i], net->ev_end[i]) != hipSuccess) return SICN_ENODEV;
-            sum += ms;
-        }
-        ms_sum[l] = sum;
-        launches[l] = net->ev_count[l];
-        if (reset) net->ev_count[l] = 0;
+    const size_t n_layers = net->descs.size();
+    for (size_t l = 0; l < n_layers; l++) {
+        ms_sum[l] = 0.f;
+        launches[l] = 0;
+    }
+    int used = net->ev_next.load(std::memory_order_acquire);
+    if (used > sicn_net::EV_RING) used = sicn_net::EV_RING;
+    if (net->ev_begin.empty()) used = 0;
+    for (int i = 0; i < used; i++) {
+        const int l = net->ev_layer[i];
+        if (l < 0 || (size_t)l >= n_layers) continue;   // reserved by a call that failed before recording
+        if (hipEventSynchronize(net->ev_end[i]) != hipSuccess) return SICN_ENODEV;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, net->ev_begin[i], net->ev_end[i]) != hipSuccess) return SICN_ENODEV;
+        ms_sum[l] += ms;
+        launches[l]++;
+    }
+    if (reset) {
+        for (int i = 0; i < used; i++) net->ev_layer[i] = -1;
+        net->ev_next.store(0, std::memory_order_release);
     }
     return SICN_OK;
 }

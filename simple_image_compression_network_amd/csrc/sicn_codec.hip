@@ -33,6 +33,11 @@ inline uint32_t stream_cap(int mode) { return mode == SICN_CODEC_RANSW ? WCAP : 
 constexpr uint32_t RANS_L = 1u << 23;
 constexpr int PROB_BITS = 12;
 constexpr uint32_t ADLER_MOD = 65521u;
+// rANS modes: ceil(n / stream symbols) * scratch capacity must stay below 2^32 (32-bit stream offsets):
+// 0x7F000000 / 16384 * 33024 = 0x7F000000 / 1024 * 2064 = 4 294 705 152 < 2^32
+constexpr uint32_t MAX_RANS_SYMBOLS = 0x7F000000u;
+static_assert((unsigned long long)(MAX_RANS_SYMBOLS / WSS) * WCAP < (1ull << 32), "mode 3 offsets would wrap");
+static_assert((unsigned long long)(MAX_RANS_SYMBOLS / SS) * CAP < (1ull << 32), "mode 2 offsets would wrap");
 
 struct Workspace {  // device pointers carved out of the caller's workspace
     uint32_t *hist;                // [256]
@@ -135,8 +140,26 @@ __global__ __launch_bounds__(256) void k_stats(const uint8_t *__restrict__ lat_,
 // global memory in whole coalesced runs.
 struct RanswTab {
     uint32_t fc[128];   // freq | cum << 16
-    float rcp[128];     // 1 / freq, rounded down a little: the quotient estimate never exceeds the true one by more than the fix-up handles
+    uint32_t rcp[128];  // m = min(2^32 - 1, floor(2^32 / freq)): umulhi(x, m) is floor(x / freq) or one less, never more (see ransw_div)
 };
+
+// Exact x / f for x < 2^32, 1 <= f <= 4096, without an integer divide.  m = floor(2^32 / f) (2^32 - 1 for f = 1)
+// satisfies m <= 2^32 / f, so e = floor(x m / 2^32) <= floor(x / f): the estimate is NEVER too large; and
+// x / f - x m / 2^32 = x (2^32 / f - m) / 2^32 < x / 2^32 < 1, so e >= floor(x / f) - 1: ONE fix-up step is enough.
+// (Round 1 used a float reciprocal whose rounded product could exceed the quotient for 295 of the 4096
+// frequencies, e.g. f = 3815, x = 250046544; tests/test_codec.py::test_ransw_div_exhaustive covers all f.)
+__host__ __device__ __forceinline__ uint32_t ransw_rcp(uint32_t f)
+{
+    return f <= 1 ? (f ? 0xFFFFFFFFu : 0u) : (uint32_t)(0x100000000ull / f);
+}
+
+__host__ __device__ __forceinline__ uint32_t ransw_div(uint32_t x, uint32_t f, uint32_t m, uint32_t &r)
+{
+    uint32_t q = (uint32_t)(((unsigned long long)x * m) >> 32);   // v_mul_hi_u32
+    r = x - q * f;
+    if (r >= f) { q++; r -= f; }
+    return q;
+}
 
 __device__ __forceinline__ void ransw_build(RanswTab &t, const uint16_t *freq, int lane)
 {
@@ -151,8 +174,8 @@ __device__ __forceinline__ void ransw_build(RanswTab &t, const uint16_t *freq, i
     const uint32_t c0 = incl - f0 - f1;
     t.fc[2 * lane] = f0 | (c0 << 16);
     t.fc[2 * lane + 1] = f1 | ((c0 + f0) << 16);
-    t.rcp[2 * lane] = f0 ? (1.0f / (float)f0) * 0.99999988f : 0.f;
-    t.rcp[2 * lane + 1] = f1 ? (1.0f / (float)f1) * 0.99999988f : 0.f;
+    t.rcp[2 * lane] = ransw_rcp(f0);
+    t.rcp[2 * lane + 1] = ransw_rcp(f1);
 }
 
 __global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__ lat_, uint32_t n, uint32_t ns,
@@ -199,12 +222,8 @@ __global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__
                 x >>= 16;
             }
             if (active) {
-                // x / f by a float estimate (never too large by more than 1, too small by at most 2) and a fix-up
-                uint32_t qq = (uint32_t)(__uint2float_rz(x) * tab.rcp[sy]);
-                uint32_t r = x - qq * f;
-                if (r >= f) { qq++; r -= f; }
-                if (r >= f) { qq++; r -= f; }
-                if (r >= f) { qq++; r -= f; }
+                uint32_t r;
+                const uint32_t qq = ransw_div(x, f, tab.rcp[sy], r);
                 x = (qq << PROB_BITS) + r + c;
             }
         }
@@ -222,9 +241,13 @@ __global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__
 __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__ payload_, const uint8_t *__restrict__ freq_bytes_,
                                                      const uint32_t *__restrict__ offsets_, uint32_t n, uint32_t ns,
                                                      uint8_t *__restrict__ lat_, uint32_t *__restrict__ err_, size_t s_slot,
-                                                     size_t s_ws, size_t s_lat)
+                                                     size_t s_ws, size_t s_lat, const uint8_t *__restrict__ payload_bytes_field_)
 {
     const uint8_t *payload = img_ptr(payload_, s_slot), *freq_bytes = img_ptr(freq_bytes_, s_slot);
+    // header field "payload bytes" of this image's container (the host has checked it against the bytes it was
+    // given): no stream may reach beyond it, whatever the untrusted length table says
+    const uint8_t *pbf = img_ptr(payload_bytes_field_, s_slot);
+    const uint32_t payload_bytes = pbf[0] | ((uint32_t)pbf[1] << 8) | ((uint32_t)pbf[2] << 16) | ((uint32_t)pbf[3] << 24);
     const uint32_t *offsets = img_ptr(offsets_, s_ws);
     uint8_t *lat = img_ptr(lat_, s_lat);
     uint32_t *err = img_ptr(err_, s_ws);
@@ -244,7 +267,8 @@ __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__
     }
     const uint32_t begin = st * WSS, cnt = min(WSS, n - begin), blocks = (cnt + 255) / 256;
     const uint32_t off = offsets[st], len = offsets[st + 1] - off;
-    if (len < 256 || (len & 1) || (off & 1) || len > WCAP) {   // streams start at even container offsets
+    if (len < 256 || (len & 1) || (off & 1) || len > WCAP ||
+        (unsigned long long)off + len > payload_bytes) {   // streams start at even container offsets
         if (lane == 0) atomicOr(err, 1u);
         return;
     }
@@ -324,9 +348,12 @@ __global__ __launch_bounds__(256) void k_rans_encode(const uint8_t *__restrict__
 // Exclusive prefix sum of `in[0..n)` into out[0..n], out[n] = total.  One workgroup of 1024 lanes:
 // wavefront-level scan with __shfl_up, wave totals combined through LDS, carry across chunks.
 // `in` may be unaligned container bytes (read byte-wise when `in_bytes` != nullptr).
+// Entries above `cap` (only possible in an untrusted container) raise `*err` and count as 0, so with
+// n * cap < 2^32 (the n_symbols limit of the rANS modes, MAX_RANS_SYMBOLS) the 32-bit sums cannot wrap.
 __global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ in_, const uint8_t *__restrict__ in_bytes_,
                                                uint32_t n, uint32_t *__restrict__ out_, uint8_t *__restrict__ table_out_,
-                                               uint8_t *__restrict__ total_out_, size_t s_ws, size_t s_slot)
+                                               uint8_t *__restrict__ total_out_, size_t s_ws, size_t s_slot, uint32_t cap,
+                                               uint32_t *__restrict__ err_)
 {
     const uint32_t *in = in_ ? img_ptr(in_, s_ws) : nullptr;
     const uint8_t *in_bytes = in_bytes_ ? img_ptr(in_bytes_, s_slot) : nullptr;
@@ -347,6 +374,10 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ in_,
                 v = p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
             } else
                 v = in[i];
+            if (v > cap) {
+                if (err_) atomicOr(img_ptr(err_, s_ws), 1u);
+                v = 0;
+            }
         }
         uint32_t incl = v;
 #pragma unroll
@@ -396,7 +427,7 @@ __global__ __launch_bounds__(256) void k_compact(const uint8_t *__restrict__ scr
 
 __global__ __launch_bounds__(256) void k_rans_decode(const uint8_t *__restrict__ payload, const uint8_t *__restrict__ freq_bytes,
                                                      const uint32_t *__restrict__ offsets, uint32_t n, uint32_t ns,
-                                                     uint8_t *__restrict__ lat, uint32_t *__restrict__ err)
+                                                     uint8_t *__restrict__ lat, uint32_t *__restrict__ err, uint32_t payload_bytes)
 {
     __shared__ uint16_t freq[128], cum[128];
     __shared__ uint8_t slot[4096];
@@ -414,6 +445,7 @@ __global__ __launch_bounds__(256) void k_rans_decode(const uint8_t *__restrict__
     const uint32_t st = blockIdx.x * 256 + threadIdx.x;
     if (st >= ns) return;
     const uint32_t begin = st * SS, cnt = min(SS, n - begin);
+    if (offsets[st + 1] > payload_bytes || offsets[st + 1] < offsets[st]) { atomicOr(err, 1u); return; }
     const uint8_t *p = payload + offsets[st], *end = payload + offsets[st + 1];
     if (end - p < 4) { atomicOr(err, 1u); return; }
     uint32_t x = p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
@@ -494,6 +526,35 @@ uint32_t adler_from_sums(unsigned long long s1, unsigned long long s2, uint32_t 
 
 }  // namespace
 
+// Host-side exhaustive check of the encoder's divide (the very function the kernel inlines): for every f in
+// [f_begin, f_end) and every state the encoder can hold when it divides (x in [2^16, f << 20)), sampled at all
+// multiples of f within +-2 of a stride walk, at both ends of the range and around every power of two.
+// Returns the number of (x, f) pairs whose quotient or remainder differs from x / f, x % f.
+extern "C" long long sicn_codec_selftest_div(uint32_t f_begin, uint32_t f_end, unsigned long long *n_checked)
+{
+    long long bad = 0;
+    unsigned long long cnt = 0;
+    for (uint32_t f = f_begin < 1 ? 1 : f_begin; f < f_end && f <= 4096; f++) {
+        const uint32_t m = ransw_rcp(f);
+        const unsigned long long hi = (unsigned long long)f << 20;        // exclusive
+        auto check = [&](unsigned long long xx) {
+            if (xx < 65536 || xx >= hi || xx > 0xFFFFFFFFull) return;
+            uint32_t r;
+            const uint32_t x = (uint32_t)xx, q = ransw_div(x, f, m, r);
+            cnt++;
+            if (q != x / f || r != x % f) bad++;
+        };
+        // every 4099th multiple of f (and its neighbours) covers the range with ~256 k..1 M probes per f
+        for (unsigned long long k = 65536 / f; k * f < hi + f; k += 4099)
+            for (long long d = -2; d <= 2; d++) check(k * f + (unsigned long long)d);
+        for (int b = 16; b <= 32; b++)
+            for (long long d = -(long long)f - 2; d <= (long long)f + 2; d++) check((1ull << b) + (unsigned long long)d);
+        for (long long d = 0; d <= 2 * (long long)f + 2; d++) { check(65536 + d); check(hi - 1 - d); }
+    }
+    if (n_checked) *n_checked = cnt;
+    return bad;
+}
+
 extern "C" size_t sicn_codec_max_bytes(int mode, uint32_t n)
 {
     const uint32_t ns = (n + stream_symbols(mode) - 1) / stream_symbols(mode);
@@ -539,6 +600,7 @@ extern "C" int sicn_codec_encode(int mode, const uint8_t *latent, uint32_t lat_w
     if (!out || !out_bytes || mode < 0 || mode > 3) return SICN_EINVAL;
     const unsigned long long n64 = (unsigned long long)lat_w * lat_h * lat_c;
     if (n64 > 0x7fffffffull || (n64 && !latent)) return SICN_EINVAL;
+    if (mode >= SICN_CODEC_RANS && n64 > MAX_RANS_SYMBOLS) return SICN_EINVAL;
     const uint32_t n = (uint32_t)n64, ss = stream_symbols(mode), ns = (n + ss - 1) / ss;
     if (out_capacity < sicn_codec_max_bytes(mode, n)) return SICN_ENOSPC;
     if (!workspace || workspace_bytes < sicn_codec_workspace_bytes(mode, n)) return SICN_ENOSPC;
@@ -599,7 +661,8 @@ extern "C" int sicn_codec_encode(int mode, const uint8_t *latent, uint32_t lat_w
             hipLaunchKernelGGL(k_ransw_encode, dim3(ns), dim3(64), 0, stream, latent, n, ns, w.freq, w.scratch, w.lens, (size_t)0, (size_t)0);
         else if (ns)
             hipLaunchKernelGGL(k_rans_encode, dim3((ns + 255) / 256), dim3(256), 0, stream, latent, n, ns, w.freq, w.scratch, w.lens);
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, w.lens, (const uint8_t *)nullptr, ns, w.offsets, table, out + 40, (size_t)0, (size_t)0);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, w.lens, (const uint8_t *)nullptr, ns, w.offsets, table, out + 40, (size_t)0, (size_t)0,
+                           0xFFFFFFFFu, (uint32_t *)nullptr);
         if (ns) hipLaunchKernelGGL(k_compact, dim3(ns), dim3(256), 0, stream, w.scratch, w.lens, w.offsets, payload, stream_cap(mode), (size_t)0, (size_t)0);
         uint32_t payload_bytes = 0;
         HIP_TRY(hipMemcpyAsync(&payload_bytes, w.offsets + ns, 4, hipMemcpyDeviceToHost, stream));
@@ -625,7 +688,7 @@ extern "C" int sicn_codec_decode(const uint8_t *container, size_t bytes, uint8_t
     if (rc) return rc;
     if (info_out) *info_out = info;
     const uint32_t n = info.n_symbols, ns = info.n_streams;
-    if (n > 0x7fffffffu) return SICN_EINVAL;
+    if (n > 0x7fffffffu || (info.mode >= SICN_CODEC_RANS && n > MAX_RANS_SYMBOLS)) return SICN_EINVAL;
     if (n && (!latent || latent_capacity < n)) return SICN_ENOSPC;
     if (!workspace || workspace_bytes < sicn_codec_workspace_bytes((int)info.mode, n)) return SICN_ENOSPC;
     Workspace w;
@@ -655,15 +718,17 @@ extern "C" int sicn_codec_decode(const uint8_t *container, size_t bytes, uint8_t
             if (sum != 4096) return SICN_EINVAL;
         }
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, (const uint32_t *)nullptr, table, ns, w.offsets,
-                           (uint8_t *)nullptr, (uint8_t *)nullptr, (size_t)0, (size_t)0);
+                           (uint8_t *)nullptr, (uint8_t *)nullptr, (size_t)0, (size_t)0, stream_cap((int)info.mode), err);
         uint32_t total = 0;
         HIP_TRY(hipMemcpyAsync(&total, w.offsets + ns, 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (total != info.payload_bytes) return SICN_EINVAL;
         if (ns && info.mode == SICN_CODEC_RANSW)
-            hipLaunchKernelGGL(k_ransw_decode, dim3(ns), dim3(64), 0, stream, payload, freq_bytes, w.offsets, n, ns, latent, err, (size_t)0, (size_t)0, (size_t)0);
+            hipLaunchKernelGGL(k_ransw_decode, dim3(ns), dim3(64), 0, stream, payload, freq_bytes, w.offsets, n, ns, latent, err, (size_t)0, (size_t)0, (size_t)0,
+                               container + 40);
         else if (ns)
-            hipLaunchKernelGGL(k_rans_decode, dim3((ns + 255) / 256), dim3(256), 0, stream, payload, freq_bytes, w.offsets, n, ns, latent, err);
+            hipLaunchKernelGGL(k_rans_decode, dim3((ns + 255) / 256), dim3(256), 0, stream, payload, freq_bytes, w.offsets, n, ns, latent, err,
+                               info.payload_bytes);
     }
     // checksum of what was decoded
     uint32_t flag = 0;
@@ -693,7 +758,7 @@ extern "C" int sicn_codec_encode_batch(int mode, const uint8_t *latents, uint32_
 {
     if (mode != SICN_CODEC_RANSW || !out || !out_bytes_host) return SICN_EINVAL;
     const unsigned long long n64 = (unsigned long long)lat_w * lat_h * lat_c;
-    if (n64 > 0x7fffffffull || (n64 && !latents)) return SICN_EINVAL;
+    if (n64 > MAX_RANS_SYMBOLS || (n64 && !latents)) return SICN_EINVAL;
     if (n_images == 0) return SICN_OK;
     const uint32_t n = (uint32_t)n64, ns = (n + WSS - 1) / WSS;
     if (slot_bytes < sicn_codec_max_bytes(mode, n) || (slot_bytes & 1)) return SICN_ENOSPC;
@@ -757,7 +822,7 @@ extern "C" int sicn_codec_encode_batch(int mode, const uint8_t *latents, uint32_
             hipLaunchKernelGGL(k_ransw_encode, dim3(ns, n_images), dim3(64), 0, stream, latents, n, ns, w[0].freq, w[0].scratch,
                                w[0].lens, (size_t)n, ws1);
         hipLaunchKernelGGL(k_scan, dim3(1, n_images), dim3(1024), 0, stream, w[0].lens, (const uint8_t *)nullptr, ns, w[0].offsets,
-                           table, out + 40, ws1, slot_bytes);
+                           table, out + 40, ws1, slot_bytes, 0xFFFFFFFFu, (uint32_t *)nullptr);
         if (ns)
             hipLaunchKernelGGL(k_compact, dim3(ns, n_images), dim3(256), 0, stream, w[0].scratch, w[0].lens, w[0].offsets, payload,
                                WCAP, ws1, slot_bytes);
@@ -801,7 +866,7 @@ extern "C" int sicn_codec_decode_batch(const uint8_t *containers, size_t slot_by
         int rc = sicn_codec_parse_header(&head[i * hb], SICN_CODEC_HEADER_BYTES, &info[i]);
         if (rc) return rc;
         if (info[i].mode != SICN_CODEC_RANSW) return SICN_EINVAL;
-        if (info[i].n_symbols != info[0].n_symbols || info[i].n_symbols > 0x7fffffffu) return SICN_EINVAL;
+        if (info[i].n_symbols != info[0].n_symbols || info[i].n_symbols > MAX_RANS_SYMBOLS) return SICN_EINVAL;
         if (info[i].n_symbols && (!latents || latent_stride < info[i].n_symbols)) return SICN_ENOSPC;
         const size_t fixed = hb + 4 * (size_t)info[i].n_streams;
         if (bytes_host[i] < fixed + info[i].payload_bytes) return SICN_EINVAL;
@@ -820,10 +885,10 @@ extern "C" int sicn_codec_decode_batch(const uint8_t *containers, size_t slot_by
     {   // one launch per stage for the whole batch (blockIdx.y = image)
         const uint8_t *freq_bytes = containers + SICN_CODEC_HEADER_BYTES, *table = freq_bytes + 256, *payload = table + 4 * (size_t)ns;
         hipLaunchKernelGGL(k_scan, dim3(1, n_images), dim3(1024), 0, stream, (const uint32_t *)nullptr, table, ns, w[0].offsets,
-                           (uint8_t *)nullptr, (uint8_t *)nullptr, ws1, slot_bytes);
+                           (uint8_t *)nullptr, (uint8_t *)nullptr, ws1, slot_bytes, WCAP, w[0].hist + 255);
         if (ns)
             hipLaunchKernelGGL(k_ransw_decode, dim3(ns, n_images), dim3(64), 0, stream, payload, freq_bytes, w[0].offsets, n, ns,
-                               latents, w[0].hist + 255, slot_bytes, ws1, latent_stride);
+                               latents, w[0].hist + 255, slot_bytes, ws1, latent_stride, containers + 40);
     }
     for (uint32_t i = 0; i < n_images; i++) {
         HIP_TRY(hipMemcpyAsync(&total[i], w[i].offsets + ns, 4, hipMemcpyDeviceToHost, stream));

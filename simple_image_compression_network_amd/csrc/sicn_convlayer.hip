@@ -288,6 +288,13 @@ extern "C" int sicn_convlayer_params_create(const sicn_convlayer_desc *d, const 
 extern "C" int sicn_conv_layer_batch(const sicn_convlayer_desc *d, const sicn_convlayer_params *p, const uint8_t *in,
                                      void *out, int reps, void *hip_stream)
 {
+    return sicn_conv_layer_batch_kernel(d, p, in, out, reps, SICN_CONVLAYER_KERNEL_AUTO, hip_stream);
+}
+
+extern "C" int sicn_conv_layer_batch_kernel(const sicn_convlayer_desc *d, const sicn_convlayer_params *p, const uint8_t *in,
+                                            void *out, int reps, int kernel, void *hip_stream)
+{
+    if (kernel != SICN_CONVLAYER_KERNEL_AUTO && kernel != SICN_CONVLAYER_KERNEL_DIRECT) return SICN_EINVAL;
     int rc = sicn_convlayer_validate(d);
     if (rc) return rc;
     if (!p || !in || !out || reps < 0 || reps > 65535) return SICN_EINVAL;
@@ -299,8 +306,7 @@ extern "C" int sicn_conv_layer_batch(const sicn_convlayer_desc *d, const sicn_co
     const size_t per_img = (size_t)d->OFM_DIM * d->OFM_DIM * d->OFM_CH;
     const size_t blocks = (per_img + 255) / 256;
     if (blocks > 0x7fffffffu) return SICN_EINVAL;
-    const char *force = getenv("SICN_CONVLAYER_GENERIC");   // tests: compare the two kernels
-    if (p->d_w_mfma && (size_t)d->IFM_DIM * d->IFM_DIM * d->IFM_CH < 0x7fffffffu && !(force && force[0] == '1')) {
+    if (p->d_w_mfma && (size_t)d->IFM_DIM * d->IFM_DIM * d->IFM_CH < 0x7fffffffu && kernel != SICN_CONVLAYER_KERNEL_DIRECT) {
         const unsigned npos = (unsigned)(d->OFM_DIM * d->OFM_DIM);
         dim3 grid((npos + 255) / 256, (unsigned)((d->OFM_CH + 63) / 64), (unsigned)reps);
         hipLaunchKernelGGL(k_convlayer_mfma, grid, dim3(256), 0, (hipStream_t)hip_stream, in, out, p->d_w_mfma, p->d_wsum,

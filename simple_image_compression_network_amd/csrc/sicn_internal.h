@@ -50,7 +50,12 @@ struct sicn_weights {
 
 namespace sicn {
 
-KernelKind pick_kernel(const sicn_layer_desc &d);
+KernelKind pick_kernel(const sicn_layer_desc &d, const sicn_options &o);
+// library defaults: zeros overridden by the SICN_* environment as it was at load time (read once)
+const sicn_options &default_options();
+// build-time experiment switches of k_mfma.hip (SICN_MFMA_VARIANT, SICN_DEBUG_KERNEL, SICN_DEBUG_EXTRA_LDS), read once
+struct DebugEnv { int mfma_variant, debug_kernel, extra_lds; };
+const DebugEnv &debug_env();
 
 // Launchers: enqueue on `stream`, return hipError_t of the launch.
 hipError_t launch_generic(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
@@ -59,11 +64,11 @@ hipError_t launch_generic(const LayerGeom &g, const sicn_weights &w, const uint8
 hipError_t launch_mfma(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
                        int n_images, hipStream_t stream, int in_layout, int out_layout);
 hipError_t launch_mfma16(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                         int n_images, hipStream_t stream, int in_layout, int out_layout);
+                         int n_images, hipStream_t stream, int in_layout, int out_layout, const sicn_options &o);
 hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream, int out_layout);
+                     int n_images, hipStream_t stream, int out_layout, const sicn_options &o);
 hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream, int in_layout);
+                     int n_images, hipStream_t stream, int in_layout, const sicn_options &o);
 
 // Host-side weight packers (pure CPU, unit-testable without a GPU).
 // w_okc: [cout][25*cin].  Returns bytes written into `dst` (size from *_bytes()).

@@ -38,14 +38,13 @@ for case in range(args.cases):
     d = LayerDesc(IFM_CH=cin, IFM_ROW=w, IFM_COL=h, OFM_CH=cout, OFM_ROW=ow, OFM_COL=oh, SIMD=simd, PE=pe,
                   W_TILES=(cout // pe) * (25 * cin // simd), transposed=tr)
     d.validate()
-    env = {}
+    env = {}                     # sicn_options fields, per call
     if rng.random() < 0.5:
-        env["SICN_STRIP_CHUNKS"] = str(int(rng.integers(1, 9)))
+        env["strip_chunks"] = int(rng.integers(1, 9))
     if rng.random() < 0.5:
-        env["SICN_TILE_X"] = str(rng.choice([16, 32]))
-    for k in ("SICN_STRIP_CHUNKS", "SICN_TILE_X"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
+        env["tile_x"] = int(rng.choice([16, 32]))
+    if rng.random() < 0.3:
+        env["split_n"] = int(rng.choice([1, 2, 4]))
     W = rng.integers(-8, 8, (cout, 5, 5, cin)).astype(np.int8)
     b = rng.integers(-128, 128, cout).astype(np.int8)
     words = sicn_ref.pack_finn_tiles(W, simd, pe)
@@ -54,7 +53,7 @@ for case in range(args.cases):
         x.reshape(-1)[::5] |= 0x80
     fpw = api.FixedPointWeights(simd, 4, pe, d.W_TILES, words)
     fn = api.deconv522 if tr else api.conv2d
-    got = fn(d, fpw, b, torch.from_numpy(x).cuda(), None, n)
+    got = fn(d, fpw, b, torch.from_numpy(x).cuda(), None, n, options=env or None)
     torch.cuda.synchronize()
     got = got.cpu().numpy()
     ref_fn = sicn_ref.deconv522_ref if tr else sicn_ref.conv2d_ref
@@ -70,12 +69,13 @@ print(f"{args.cases - bad}/{args.cases} cases bit-exact")
 from simple_image_compression_network_amd.config import eight_layer_descs  # noqa: E402
 cbad = 0
 for case in range(args.chains):
-    for k in ("SICN_STRIP_CHUNKS", "SICN_TILE_X"):
-        os.environ.pop(k, None)
+    env = {}
     if rng.random() < 0.5:
-        os.environ["SICN_TILE_X"] = str(rng.choice([16, 32]))
+        env["tile_x"] = int(rng.choice([16, 32]))
     if rng.random() < 0.5:
-        os.environ["SICN_STRIP_CHUNKS"] = str(int(rng.integers(1, 6)))
+        env["strip_chunks"] = int(rng.integers(1, 6))
+    if rng.random() < 0.3:
+        env["split_n"] = int(rng.choice([1, 2, 4]))
     w, h, n = int(rng.integers(1, 26)) * 16, int(rng.integers(1, 20)) * 16, int(rng.integers(1, 3))
     descs = eight_layer_descs(w, h)
     params_np, params = [], []
@@ -85,7 +85,7 @@ for case in range(args.chains):
         params_np.append((Wt, bt, d.transposed))
         params.append((api.FixedPointWeights(d.SIMD, 4, d.PE, d.W_TILES, sicn_ref.pack_finn_tiles(Wt, d.SIMD, d.PE)),
                        api.FixedPointWeights(1, 8, 1, d.OFM_CH, bt.view(np.uint8).astype(np.uint64))))
-    net = api.EightLayersNet(w, h, params=params)
+    net = api.EightLayersNet(w, h, params=params, options=env or None)
     x = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
     out, lat = net.forward(torch.from_numpy(x).cuda())
     torch.cuda.synchronize()
@@ -96,7 +96,7 @@ for case in range(args.chains):
         ok = ok and np.array_equal(out[i], ref[7]) and np.array_equal(lat[i], ref[3])
     if not ok:
         cbad += 1
-        print(f"CHAIN MISMATCH {case}: {w}x{h} n={n} env={dict((k, os.environ.get(k)) for k in ('SICN_TILE_X', 'SICN_STRIP_CHUNKS'))}", flush=True)
+        print(f"CHAIN MISMATCH {case}: {w}x{h} n={n} env={env}", flush=True)
     elif case % 5 == 0:
         print(f"chain {case}: ok ({w}x{h} n={n})", flush=True)
 if args.chains:

@@ -67,3 +67,22 @@ def test_null_arguments_are_rejected_without_touching_the_gpu():
     assert L.sicn_conv2d(ctypes.byref(d), None, None, None, 1, None) == -22
     assert L.sicn_net_create(None, None, 0, ctypes.byref(out)) == -22
     assert L.sicn_net_workspace_bytes(None, 1) == 0
+
+
+def test_options_defaults_and_validation_without_gpu():
+    """sicn_options: plain data per call / per net; defaults come from sicn_options_init; out-of-range fields are
+    rejected before anything touches the GPU (the library has no process-wide switches any more)."""
+    L = _lib.lib()
+    o = _lib.COptions()
+    L.sicn_options_init(ctypes.byref(o))
+    assert o.struct_bytes == ctypes.sizeof(_lib.COptions) == 64
+    assert (o.force_generic, o.strip_chunks, o.no_phase_layout) == (0, 0, 0)
+    d = REFERENCE_DESCS[1].to_c()
+    out = ctypes.c_void_p()
+    for field, bad in (("mfma_shape", 8), ("tile_x", 24), ("strip_chunks", -1), ("no_phase_layout", 3), ("split_n", 7),
+                       ("struct_bytes", 4), ("struct_bytes", 4096)):
+        o = _lib.make_options()
+        setattr(o, field, bad)
+        assert L.sicn_conv2d_opt(ctypes.byref(d), None, None, None, 1, ctypes.byref(o), None) == -22
+        assert L.sicn_net_create_opt(ctypes.byref(d), ctypes.byref(out), 1, ctypes.byref(o), ctypes.byref(out)) == -22
+    assert not hasattr(L, "sicn_set_force_generic")

@@ -123,8 +123,93 @@ def test_codec_abi_symbols_exported():
     assert _lib.lib().sicn_codec_parse_header(buf, 10, ctypes.byref(info)) == -22
 
 
+def test_ransw_div_exhaustive():
+    """The rANS-W encoder divides by a 32-bit fixed-point reciprocal (csrc/sicn_codec.hip: ransw_div). The library
+    checks that very function on the host for EVERY frequency 1..4096 over the states an encoder lane can hold
+    (x in [2^16, f << 20)): neighbourhoods of multiples of f across the range, both ends, every power of two.
+    Round 1's float reciprocal failed this for 295 frequencies (e.g. f = 3815, x = 250046544)."""
+    from simple_image_compression_network_amd import _lib
+    n = ctypes.c_ulonglong(0)
+    assert _lib.lib().sicn_codec_selftest_div(1, 4097, ctypes.byref(n)) == 0
+    assert n.value > 4096 * 50_000
+    # and the same arithmetic restated in numpy for the advisor's counterexample and its neighbours
+    for f, x in ((3815, 250046544), (181, 181 << 19), (343, 343 * 70001), (405, 405 * 1000003)):
+        m = min(0xFFFFFFFF, (1 << 32) // f)
+        for xx in range(x - 3, x + 4):
+            q = (xx * m) >> 32
+            assert q in (xx // f, xx // f - 1) and q <= xx // f
+
+
+def _skewed_latent(rng, n, dominant_p, mid=(300, 1000)):
+    """One dominant symbol with 12-bit frequency ~ dominant_p * 4096 (3700..4095 hits the reciprocals the float
+    estimate got wrong), a few mid-frequency symbols, a tail of rare ones."""
+    p = np.zeros(128)
+    p[0] = dominant_p
+    rest = 1.0 - dominant_p
+    mids = rng.choice(np.arange(1, 128), 4, replace=False)
+    p[mids] = rest * 0.7 / 4
+    others = np.setdiff1d(np.arange(1, 128), mids)
+    p[others] = rest * 0.3 / others.size
+    return rng.choice(128, n, p=p / p.sum()).astype(np.uint8)
+
+
 # ------------------------------------------------------------------------------------------ GPU
 gpu = pytest.mark.gpu
+
+
+@gpu
+@pytest.mark.parametrize("dominant_p", [0.905, 0.9313, 0.96, 0.99, 0.999, 0.08, 0.25])
+def test_gpu_ransw_equals_oracle_on_skewed_latents(dominant_p):
+    """>= 4 M symbols per case, dominant frequencies 3700..4095 and mid frequencies 300..1000: the GPU container
+    must equal the oracle's (exact x / f) byte for byte and decode back (float reciprocal overshoot)."""
+    import torch
+    from simple_image_compression_network_amd import codec
+    rng = np.random.default_rng(int(dominant_p * 1e4))
+    n = 135 * 240 * 192 if dominant_p < 0.9 else 4 * 1024 * 1024 + 12345
+    sym = _skewed_latent(rng, n, dominant_p) if dominant_p >= 0.9 else np.minimum(
+        rng.geometric(dominant_p, n) - 1, 127).astype(np.uint8)        # natural-like: geometric magnitudes
+    lat = sym.reshape(1, 1, -1) if dominant_p >= 0.9 else sym.reshape(135, 240, 192)
+    dev = torch.from_numpy(lat).cuda()
+    blob = codec.encode_latent(dev, 0, 0, codec.RANSW)
+    ref = c_oracle.codec_encode(lat, (0, 0), 3)
+    assert blob.cpu().numpy().tobytes() == ref
+    back, _ = codec.decode_latent(blob)
+    assert torch.equal(back, dev)
+
+
+@gpu
+def test_gpu_decode_rejects_hostile_length_tables():
+    """The per-stream length table is untrusted: entries that are huge, that wrap a 32-bit sum back onto
+    payload_bytes, or that point past the payload must give SICN_EINVAL (never a GPU fault), in the single and
+    in the batch path."""
+    import torch
+    from simple_image_compression_network_amd import _lib, codec
+    rng = np.random.default_rng(33)
+    lat = np.stack([_mock_latent(rng, (9, 10, 192)) for _ in range(3)])    # 17280 symbols: 2 wave streams each
+    dev = torch.from_numpy(lat).cuda()
+    slots, sizes = codec.encode_latents(dev, 160, 144)
+    tab = 48 + 256                                                          # offset of the u32 length table
+    good = slots[1, tab:tab + 8].cpu().numpy().copy().view("<u4")
+    pb = int(good.sum())
+
+    def patched(entries):
+        s = slots.clone()
+        s[1, tab:tab + 8] = torch.from_numpy(np.array(entries, "<u4").view(np.uint8).copy()).cuda()
+        return s
+
+    hostile = [[0xFFFF0000, (pb - 0xFFFF0000) % (1 << 32)],     # wraps to payload_bytes mod 2^32
+               [0xFFFFFFFF, 1 + pb], [pb + 2, 0xFFFFFFFE], [int(good[0]), 0x40000000], [0x7FFFFFF0, 0x7FFFFFF0],
+               [int(good[0]) + 2, int(good[1]) - 2]]               # plausible sizes, wrong split
+    for entries in hostile:
+        bad = patched(entries)
+        with pytest.raises(_lib.SicnError) as e:
+            codec.decode_latents(bad, sizes)
+        assert e.value.code in (-22, -74), entries
+        with pytest.raises(_lib.SicnError) as e:
+            codec.decode_latent(bad[1, :sizes[1]].clone())
+        assert e.value.code in (-22, -74), entries
+    back, _ = codec.decode_latents(slots, sizes)                             # the device still works afterwards
+    assert torch.equal(back, dev)
 
 
 @gpu

@@ -110,9 +110,9 @@ def test_gpu_conv_layer_batch_matches_oracle(case):
 
 
 @pytest.mark.gpu
-def test_gpu_mfma_and_direct_kernels_agree(monkeypatch):
+def test_gpu_mfma_and_direct_kernels_agree():
     """The same layer through k_convlayer_mfma (default when IFM_CH % 16 == 0) and through the direct kernel
-    (SICN_CONVLAYER_GENERIC=1), on a shape large enough for several workgroups."""
+    (sicn_conv_layer_batch_kernel(..., SICN_CONVLAYER_KERNEL_DIRECT)), on a shape large enough for several workgroups."""
     import torch
     from simple_image_compression_network_amd.api import FixedPointWeights
     from simple_image_compression_network_amd.convlayer import ConvLayer_Batch, ConvLayerDesc, PassThroughActivation
@@ -125,8 +125,7 @@ def test_gpu_mfma_and_direct_kernels_agree(monkeypatch):
     x = torch.from_numpy(rng.integers(0, 256, (3, D, D, C), dtype=np.uint8)).cuda()
     fpw = FixedPointWeights(8, 4, 8, desc.W_TILES, words)
     a = ConvLayer_Batch(desc, x, None, fpw, act, 3).clone()
-    monkeypatch.setenv("SICN_CONVLAYER_GENERIC", "1")
-    b = ConvLayer_Batch(desc, x, None, fpw, act, 3)
+    b = ConvLayer_Batch(desc, x, None, fpw, act, 3, kernel=1)
     assert torch.equal(a, b)
     ref = sicn_ref.conv_layer_batch_ref(x[1].cpu().numpy(), w, K, False, 24, True, 32)
     assert np.array_equal(a[1].cpu().numpy().astype(np.int64) & 0xFFFFFFFF, ref.astype(np.int64))

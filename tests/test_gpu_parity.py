@@ -53,10 +53,11 @@ def _rand_params(rng, d):
     return W, b, sicn_ref.pack_finn_tiles(W, d.SIMD, d.PE)
 
 
-def _run_layer(api, d, words, b, x_np):
+def _run_layer(api, d, words, b, x_np, **options):
+    """options: sicn_options fields (per call; the library keeps no process-wide knobs)."""
     fpw = api.FixedPointWeights(d.SIMD, 4, d.PE, d.W_TILES, words)
     fn = api.deconv522 if d.transposed else api.conv2d
-    out = fn(d, fpw, b, _dev(x_np), None, x_np.shape[0])
+    out = fn(d, fpw, b, _dev(x_np), None, x_np.shape[0], options=options or None)
     torch.cuda.synchronize()
     return out.cpu().numpy()
 
@@ -97,15 +98,14 @@ def test_layer_matches_oracle_random_weights(api, case):
 
 @pytest.mark.parametrize("chunks", ["1", "2", "5"])
 @pytest.mark.parametrize("case", [(3, 128, 3, 8, 140, 150, 0), (128, 3, 8, 3, 70, 45, 1), (128, 3, 8, 3, 64, 32, 1)])
-def test_strip_kernels_long_strips(api, case, chunks, monkeypatch):
+def test_strip_kernels_long_strips(api, case, chunks):
     """L0 / L7 walk a vertical strip per workgroup (L7 through a rolling LDS window); force long strips
     on small images so that ring wrap-around, chunk boundaries and the last partial step are covered."""
-    monkeypatch.setenv("SICN_STRIP_CHUNKS", chunks)
     rng = np.random.default_rng(abs(hash(case)) % (1 << 32))
     d = _mk_desc(*case)
     W, b, words = _rand_params(rng, d)
     x = rng.integers(0, 256 if d.IFM_CH == 3 else 128, (2,) + d.in_shape, dtype=np.uint8)
-    got = _run_layer(api, d, words, b, x)
+    got = _run_layer(api, d, words, b, x, strip_chunks=int(chunks))
     ref_fn = sicn_ref.deconv522_ref if d.transposed else sicn_ref.conv2d_ref
     for i in range(2):
         ref = ref_fn(x[i], W, b)
@@ -116,15 +116,14 @@ MFMA_CASES = [c for c in SPECIAL if c[0] != 3 and c[1] != 3]
 
 
 @pytest.mark.parametrize("case", MFMA_CASES)
-def test_32x32x32_kernels_match_oracle(api, case, monkeypatch):
-    """k_mfma.hip (v_mfma_i32_32x32x32_i8) is kept as a second implementation of L1-L6, selected per launch
-    by SICN_MFMA_SHAPE=32: it must stay bit-exact too, standalone and inside a chain (internal layouts)."""
-    monkeypatch.setenv("SICN_MFMA_SHAPE", "32")
+def test_32x32x32_kernels_match_oracle(api, case):
+    """k_mfma.hip (v_mfma_i32_32x32x32_i8) is kept as a second implementation of L1-L6, selected per call
+    by sicn_options.mfma_shape = 32: it must stay bit-exact too, standalone and inside a chain (internal layouts)."""
     rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + 5)
     d = _mk_desc(*case)
     W, b, words = _rand_params(rng, d)
     x = rng.integers(0, 128, (2,) + d.in_shape, dtype=np.uint8)
-    got = _run_layer(api, d, words, b, x)
+    got = _run_layer(api, d, words, b, x, mfma_shape=32)
     ref_fn = sicn_ref.deconv522_ref if d.transposed else sicn_ref.conv2d_ref
     for i in range(2):
         assert np.array_equal(got[i], ref_fn(x[i], W, b))
@@ -132,35 +131,32 @@ def test_32x32x32_kernels_match_oracle(api, case, monkeypatch):
 
 @pytest.mark.parametrize("tile_x", ["16", "32"])
 @pytest.mark.parametrize("case", MFMA_CASES + [(128, 128, 8, 16, 50, 20, 0), (192, 128, 12, 16, 37, 21, 1), (128, 192, 8, 24, 47, 18, 0)])
-def test_both_tile_widths_match_oracle(api, case, tile_x, monkeypatch):
+def test_both_tile_widths_match_oracle(api, case, tile_x):
     """The 16x16x64 kernels exist for 8 x 32 and 8 x 16 position tiles (the launcher picks by layer shape and
     grid size); force each one on every shape."""
-    monkeypatch.setenv("SICN_TILE_X", tile_x)
     rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + int(tile_x))
     d = _mk_desc(*case)
     W, b, words = _rand_params(rng, d)
     x = rng.integers(0, 128, (2,) + d.in_shape, dtype=np.uint8)
-    got = _run_layer(api, d, words, b, x)
+    got = _run_layer(api, d, words, b, x, tile_x=int(tile_x))
     ref_fn = sicn_ref.deconv522_ref if d.transposed else sicn_ref.conv2d_ref
     for i in range(2):
         assert np.array_equal(got[i], ref_fn(x[i], W, b))
 
 
 @pytest.mark.parametrize("tile_x", ["16", "32"])
-def test_both_tile_widths_in_chain(api, tile_x, monkeypatch):
-    monkeypatch.setenv("SICN_TILE_X", tile_x)
+def test_both_tile_widths_in_chain(api, tile_x):
     xin = _dev(_input("rng768")[None])
-    net = api.EightLayersNet(768, 512)
+    net = api.EightLayersNet(768, 512, options={"tile_x": int(tile_x)})
     out, latent = net.forward(xin)
     torch.cuda.synchronize()
     assert _sha(out[0].cpu().numpy()) == HASHES["layers"]["rng768"][7]
     assert _sha(latent[0].cpu().numpy()) == HASHES["layers"]["rng768"][3]
 
 
-def test_32x32x32_kernels_in_chain(api, monkeypatch):
-    monkeypatch.setenv("SICN_MFMA_SHAPE", "32")
+def test_32x32x32_kernels_in_chain(api):
     xin = _dev(_input("rng256")[None])
-    net = api.EightLayersNet(256, 256)
+    net = api.EightLayersNet(256, 256, options={"mfma_shape": 32})
     out, latent = net.forward(xin)
     torch.cuda.synchronize()
     assert _sha(out[0].cpu().numpy()) == HASHES["layers"]["rng256"][7]
@@ -178,13 +174,50 @@ def test_specialised_and_generic_kernels_agree(api):
         x = rng.integers(0, 128, (1,) + d.in_shape, dtype=np.uint8)
         assert L.sicn_kernel_for(ctypes.byref(d.to_c())) != b"generic"
         fast = _run_layer(api, d, words, b, x)
-        L.sicn_set_force_generic(1)
-        try:
-            assert L.sicn_kernel_for(ctypes.byref(d.to_c())) == b"generic"
-            slow = _run_layer(api, d, words, b, x)
-        finally:
-            L.sicn_set_force_generic(0)
+        slow = _run_layer(api, d, words, b, x, force_generic=1)     # per call: no process-wide switch exists
+        assert L.sicn_kernel_for(ctypes.byref(d.to_c())) != b"generic"
         assert np.array_equal(fast, slow)
+
+
+def test_two_streams_one_net_with_profiling(api):
+    """sicn.h: handles are immutable, launches on different streams (and host threads) may run concurrently, each
+    with its own workspace; the profiling ring hands out slots atomically. Two host threads drive two streams through
+    ONE net handle with profiling on; every result must be exact and every launch must be accounted for."""
+    import threading
+    net = api.EightLayersNet(256, 256)
+    net.profile(True)
+    rng = np.random.default_rng(5)
+    xs = [_dev(rng.integers(0, 256, (2, 256, 256, 3), dtype=np.uint8)) for _ in range(2)]
+    ref = [net.forward(x)[0].clone() for x in xs]
+    torch.cuda.synchronize()
+    net.layer_ms(reset=True)
+    L = api._lib.lib()
+    nbytes = L.sicn_net_workspace_bytes(net._h, 2)
+    ws = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    outs = [torch.empty_like(ref[0]) for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    iters, errs = 40, []
+
+    def worker(k):
+        try:
+            for _ in range(iters):
+                rc = L.sicn_eight_layers_net(net._h, ctypes.c_void_p(xs[k].data_ptr()), ctypes.c_void_p(outs[k].data_ptr()),
+                                             None, 2, ctypes.c_void_p(ws[k].data_ptr()), nbytes,
+                                             ctypes.c_void_p(streams[k].cuda_stream))
+                if rc:
+                    errs.append(rc)
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    assert not errs
+    assert torch.equal(outs[0], ref[0]) and torch.equal(outs[1], ref[1])
+    ms, cnt = net.layer_ms(reset=True)
+    assert cnt == [2 * iters] * 8 and all(m > 0 for m in ms)
+    net.profile(False)
 
 
 def _input(name):
@@ -372,6 +405,10 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_images"] == 4
     assert d["value"] > 0 and "cpu_baseline" not in d and d["roofline"]["frac"] > 0
+    # two distinct shards ran (seeds differ per global image) and both went through the coder round trip
+    assert len(d["rank_checksums"]) == 2 and d["rank_checksums"][0] != d["rank_checksums"][1]
+    assert d["output_bit_exact"] is None                 # no golden hashes for this rehearsal size
+    assert d["with_coder"]["round_trip_exact"] is True and d["with_coder"]["value"] > 0
 
 
 def test_committed_small_vectors_on_gpu(api):
