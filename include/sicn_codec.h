@@ -23,8 +23,8 @@
  *                    Lane l owns 4 consecutive symbols of every 256-symbol block.  Same frequency table as
  *                    mode 2; on a 4K latent the kernels are 6-7x faster (≈55 us each way), +0.8 % bytes
  *
- * All pointers are DEVICE pointers unless named *_host.  Unlike sicn.h's launch functions, these
- * calls synchronise `hip_stream` (sizes have to come back to the caller).
+ * All pointers are DEVICE pointers unless named *_host.  Unlike sicn.h's launch functions, the plain
+ * calls synchronise `hip_stream` (sizes have to come back to the caller); the *_async pair does not.
  */
 #ifndef SICN_CODEC_H
 #define SICN_CODEC_H
@@ -69,7 +69,8 @@ int sicn_codec_decode(const uint8_t *container, size_t bytes, uint8_t *latent, s
 
 /* Batches (mode SICN_CODEC_RANSW only): n_images latents of one shape, `latents` = [n][lat_h][lat_w][lat_c], container i
  * at `out + i * slot_bytes` (slot_bytes >= sicn_codec_max_bytes, even), its size in out_bytes_host[i].  Byte-identical
- * to n single calls, with two host synchronisations per batch instead of three per image. */
+ * to n single calls.  Wrappers around the asynchronous pair below: one host synchronisation per encode batch (the
+ * sizes come back), two per decode batch (the shape is read from the headers first). */
 size_t sicn_codec_batch_workspace_bytes(int mode, uint32_t n_symbols, uint32_t n_images);
 int sicn_codec_encode_batch(int mode, const uint8_t *latents, uint32_t n_images, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c,
                             uint32_t image_width, uint32_t image_height, uint8_t *out, size_t slot_bytes,
@@ -78,6 +79,27 @@ int sicn_codec_encode_batch(int mode, const uint8_t *latents, uint32_t n_images,
 int sicn_codec_decode_batch(const uint8_t *containers, size_t slot_bytes, const size_t *bytes_host, uint32_t n_images,
                             uint8_t *latents, size_t latent_stride, sicn_codec_info *infos_or_null, void *workspace,
                             size_t workspace_bytes, void *hip_stream);
+
+/* Asynchronous batch pair (rANS-W): everything — statistics, the 12-bit frequency table, header, streams, stream
+ * offsets, compaction; header / table validation, streams, checksum — runs on the device.  The calls only enqueue
+ * work on hip_stream: no host synchronisation, no allocation, capturable in a hipGraph.  Results are reported in
+ * DEVICE memory: status[i].error == 0 on success (encode: bit 0 = a symbol >= 128, bit 1 = no valid frequency
+ * table; decode: bits 2-6 = malformed container (SICN_EINVAL), bit 7 = checksum mismatch (SICN_EBADMSG), bit 8 =
+ * slot shorter than its fixed part), status[i].bytes = container size (encode) / symbols decoded (decode).
+ * Containers are byte-identical to sicn_codec_encode / sicn_codec_encode_batch and to the oracle.
+ * The decoder takes the latent shape from the CALLER (a container whose header disagrees is an error) and, optionally,
+ * the number of valid bytes of each slot from a device array (e.g. the encoder's status array); NULL = slot_bytes. */
+typedef struct sicn_codec_status {
+    uint32_t error;
+    uint32_t bytes;
+} sicn_codec_status;
+int sicn_codec_encode_batch_async(const uint8_t *latents, uint32_t n_images, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c,
+                                  uint32_t image_width, uint32_t image_height, uint8_t *out, size_t slot_bytes,
+                                  sicn_codec_status *status_dev, void *workspace, size_t workspace_bytes, void *hip_stream);
+int sicn_codec_decode_batch_async(const uint8_t *containers, size_t slot_bytes, const sicn_codec_status *valid_dev_or_null,
+                                  uint32_t n_images, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c, uint8_t *latents,
+                                  size_t latent_stride, sicn_codec_status *status_dev, void *workspace, size_t workspace_bytes,
+                                  void *hip_stream);
 
 /* Self-test (host arithmetic only, no GPU): checks the rANS-W encoder's reciprocal divide against x / f for
  * f in [f_begin, f_end) over the states the encoder can hold. Returns the number of wrong results (0 = pass). */

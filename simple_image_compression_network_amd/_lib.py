@@ -92,6 +92,8 @@ CODEC_ABI = {
     "sicn_codec_batch_workspace_bytes": (_sz, [_i, _u32, _u32]),
     "sicn_codec_encode_batch": (_i, [_i, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _sz, ctypes.POINTER(_sz), _vp, _sz, _vp]),
     "sicn_codec_decode_batch": (_i, [_vp, _sz, ctypes.POINTER(_sz), _u32, _vp, _sz, ctypes.POINTER(CodecInfo), _vp, _sz, _vp]),
+    "sicn_codec_encode_batch_async": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _sz, _vp, _vp, _sz, _vp]),
+    "sicn_codec_decode_batch_async": (_i, [_vp, _sz, _vp, _u32, _u32, _u32, _u32, _vp, _sz, _vp, _vp, _sz, _vp]),
     "sicn_codec_selftest_div": (ctypes.c_longlong, [_u32, _u32, ctypes.POINTER(ctypes.c_ulonglong)]),
 }
 

@@ -10,7 +10,7 @@ from . import _lib
 
 RAW8, PACKED7, RANS, RANSW = 0, 1, 2, 3
 __all__ = ["RAW8", "PACKED7", "RANS", "RANSW", "encode_latent", "decode_latent", "parse_header", "encode_latents",
-           "decode_latents"]
+           "decode_latents", "LatentCoder"]
 
 
 def _stream_ptr(stream):
@@ -94,3 +94,66 @@ def decode_latents(slots, sizes, stream=None):
                                          max(n, 1), infos, ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr(stream)),
                "sicn_codec_decode_batch")
     return latents, list(infos)
+
+
+class LatentCoder:
+    """The asynchronous rANS-W batch pair (sicn_codec_encode_batch_async / sicn_codec_decode_batch_async) with its
+    buffers allocated once: n latents of one shape per call, nothing but kernel launches on the current stream — no
+    host synchronisation, so analysis -> encode -> decode -> synthesis can be enqueued back to back (or captured in
+    one hipGraph).  Verdicts and sizes stay on the device until `check()` / `sizes()` fetch them."""
+
+    def __init__(self, n_images: int, lat_h: int, lat_w: int, lat_c: int, image_width: int = 0, image_height: int = 0,
+                 device="cuda"):
+        import torch
+        L = _lib.lib()
+        self.shape = (int(n_images), int(lat_h), int(lat_w), int(lat_c))
+        self.image_wh = (int(image_width), int(image_height))
+        n = lat_h * lat_w * lat_c
+        self.slot = (int(L.sicn_codec_max_bytes(RANSW, n)) + 255) // 256 * 256
+        dev = torch.device(device)
+        self.slots = torch.empty((n_images, self.slot), dtype=torch.uint8, device=dev)
+        self.ws = torch.empty(max(L.sicn_codec_batch_workspace_bytes(RANSW, n, n_images), 256), dtype=torch.uint8, device=dev)
+        self.enc_status = torch.zeros((n_images, 2), dtype=torch.int32, device=dev)   # sicn_codec_status {error, bytes}
+        self.dec_status = torch.zeros((n_images, 2), dtype=torch.int32, device=dev)
+
+    def encode(self, latents, stream=None):
+        """latents: CUDA uint8 [n][h][w][c] -> self.slots (containers), self.enc_status. Enqueue only."""
+        import torch
+        if not (latents.is_cuda and latents.dtype == torch.uint8 and latents.is_contiguous() and tuple(latents.shape) == self.shape):
+            raise TypeError(f"latents must be a contiguous CUDA uint8 tensor of shape {self.shape}")
+        n, h, w, c = self.shape
+        _lib.check(_lib.lib().sicn_codec_encode_batch_async(
+            ctypes.c_void_p(latents.data_ptr()), n, w, h, c, self.image_wh[0], self.image_wh[1],
+            ctypes.c_void_p(self.slots.data_ptr()), self.slot, ctypes.c_void_p(self.enc_status.data_ptr()),
+            ctypes.c_void_p(self.ws.data_ptr()), self.ws.numel(), _stream_ptr(stream)), "sicn_codec_encode_batch_async")
+        return self.slots
+
+    def decode(self, out_latents, slots=None, valid=None, stream=None):
+        """slots (default: self.slots) -> out_latents [n][h][w][c], self.dec_status. `valid`: device int32 [n][2] status
+        array whose `.bytes` bound each slot (default: the encoder's); pass False to trust the whole slot. Enqueue only."""
+        import torch
+        n, h, w, c = self.shape
+        slots = self.slots if slots is None else slots
+        if not (out_latents.is_cuda and out_latents.dtype == torch.uint8 and out_latents.is_contiguous() and tuple(out_latents.shape) == self.shape):
+            raise TypeError(f"out_latents must be a contiguous CUDA uint8 tensor of shape {self.shape}")
+        if not (slots.is_cuda and slots.dtype == torch.uint8 and slots.is_contiguous() and tuple(slots.shape) == (n, self.slot)):
+            raise TypeError("slots must be a contiguous CUDA uint8 tensor [n][slot_bytes]")
+        vptr = None if valid is False else ctypes.c_void_p((self.enc_status if valid is None else valid).data_ptr())
+        _lib.check(_lib.lib().sicn_codec_decode_batch_async(
+            ctypes.c_void_p(slots.data_ptr()), self.slot, vptr, n, w, h, c, ctypes.c_void_p(out_latents.data_ptr()), h * w * c,
+            ctypes.c_void_p(self.dec_status.data_ptr()), ctypes.c_void_p(self.ws.data_ptr()), self.ws.numel(), _stream_ptr(stream)),
+            "sicn_codec_decode_batch_async")
+        return out_latents
+
+    def sizes(self):
+        """Container sizes of the last encode (synchronises)."""
+        return [int(v) for v in self.enc_status[:, 1].cpu().tolist()]
+
+    def check(self):
+        """Raises SicnError if the last encode / decode reported an error (synchronises)."""
+        e = self.enc_status[:, 0].cpu().tolist()
+        d = self.dec_status[:, 0].cpu().tolist()
+        if any(e):
+            raise _lib.SicnError(-22, f"rANS-W encode status {e}")
+        if any(d):
+            raise _lib.SicnError(-22 if any(v & ~128 for v in d) else -74, f"rANS-W decode status {d}")

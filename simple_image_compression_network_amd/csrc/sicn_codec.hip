@@ -43,6 +43,7 @@ struct Workspace {  // device pointers carved out of the caller's workspace
     uint32_t *hist;                // [256]
     unsigned long long *sums;      // [2]: sum d_i, sum (n-i) d_i, both reduced mod 65521 per lane
     uint16_t *freq;                // [128]
+    uint32_t *meta;                // [16] async paths: [0] error flags, [1] sanitised payload bytes, [2] header adler32
     uint32_t *lens;                // [ns]
     uint32_t *offsets;             // [ns + 1]
     uint8_t *scratch;              // [ns][CAP]
@@ -57,6 +58,7 @@ size_t carve(Workspace &w, void *base, uint32_t ns, size_t scratch_per_stream)
     w.hist = (uint32_t *)(p + off); off += 1024;
     w.sums = (unsigned long long *)(p + off); off += 64;
     w.freq = (uint16_t *)(p + off); off += 256;
+    w.meta = (uint32_t *)(p + off); off += 64;
     w.lens = (uint32_t *)(p + off); off += align_up(4 * (size_t)ns + 4, 64);
     w.offsets = (uint32_t *)(p + off); off += align_up(4 * (size_t)ns + 4, 64);
     w.scratch = p + off;
@@ -210,10 +212,13 @@ __global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__
         if (q) nxt = load4(q - 1);   // the next block's symbols are in flight while this one is coded
 #pragma unroll
         for (int k = 3; k >= 0; k--) {
-            const bool active = q * 256 + lane * 4 + k < cnt;
-            const uint32_t sy = (sym4 >> (8 * k)) & 255u;
+            const bool active0 = q * 256 + lane * 4 + k < cnt;
+            const uint32_t sy = (sym4 >> (8 * k)) & 127u;   // symbols >= 128 are an error flagged by the statistics stage
             const uint32_t t = tab.fc[sy];
-            const uint32_t f = active ? (t & 0xFFFFu) : 1u, c = t >> 16;
+            const uint32_t c = t >> 16;
+            uint32_t f = t & 0xFFFFu;
+            const bool active = active0 && f != 0;          // f == 0 only for a latent the header stage rejected
+            f = active ? f : 1u;
             const bool emit = active && (unsigned long long)x >= ((unsigned long long)f << 20);
             const unsigned long long mask = __ballot(emit);
             pos -= (uint32_t)__popcll(mask);
@@ -241,13 +246,15 @@ __global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__
 __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__ payload_, const uint8_t *__restrict__ freq_bytes_,
                                                      const uint32_t *__restrict__ offsets_, uint32_t n, uint32_t ns,
                                                      uint8_t *__restrict__ lat_, uint32_t *__restrict__ err_, size_t s_slot,
-                                                     size_t s_ws, size_t s_lat, const uint8_t *__restrict__ payload_bytes_field_)
+                                                     size_t s_ws, size_t s_lat, const uint8_t *__restrict__ payload_bytes_field_,
+                                                     const uint32_t *__restrict__ meta_)
 {
     const uint8_t *payload = img_ptr(payload_, s_slot), *freq_bytes = img_ptr(freq_bytes_, s_slot);
     // header field "payload bytes" of this image's container (the host has checked it against the bytes it was
     // given): no stream may reach beyond it, whatever the untrusted length table says
     const uint8_t *pbf = img_ptr(payload_bytes_field_, s_slot);
-    const uint32_t payload_bytes = pbf[0] | ((uint32_t)pbf[1] << 8) | ((uint32_t)pbf[2] << 16) | ((uint32_t)pbf[3] << 24);
+    uint32_t payload_bytes = pbf[0] | ((uint32_t)pbf[1] << 8) | ((uint32_t)pbf[2] << 16) | ((uint32_t)pbf[3] << 24);
+    if (meta_) payload_bytes = min(payload_bytes, img_ptr(meta_, s_ws)[1]);   // async path: clamped by the parse stage
     const uint32_t *offsets = img_ptr(offsets_, s_ws);
     uint8_t *lat = img_ptr(lat_, s_lat);
     uint32_t *err = img_ptr(err_, s_ws);
@@ -353,8 +360,11 @@ __global__ __launch_bounds__(256) void k_rans_encode(const uint8_t *__restrict__
 __global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ in_, const uint8_t *__restrict__ in_bytes_,
                                                uint32_t n, uint32_t *__restrict__ out_, uint8_t *__restrict__ table_out_,
                                                uint8_t *__restrict__ total_out_, size_t s_ws, size_t s_slot, uint32_t cap,
-                                               uint32_t *__restrict__ err_)
+                                               uint32_t *__restrict__ err_, uint32_t *__restrict__ status_bytes_ = nullptr,
+                                               uint32_t fixed_bytes = 0, const uint32_t *__restrict__ skip_meta_ = nullptr)
 {
+    // async decode: a slot the parse stage found shorter than its own fixed part (meta[0] & 0x100) is never read
+    const bool skip = skip_meta_ && (img_ptr(skip_meta_, s_ws)[0] & 0x100u);
     const uint32_t *in = in_ ? img_ptr(in_, s_ws) : nullptr;
     const uint8_t *in_bytes = in_bytes_ ? img_ptr(in_bytes_, s_slot) : nullptr;
     uint32_t *out = img_ptr(out_, s_ws);
@@ -368,7 +378,7 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ in_,
     for (uint32_t base = 0; base < n; base += 1024) {
         const uint32_t i = base + threadIdx.x;
         uint32_t v = 0;
-        if (i < n) {
+        if (i < n && !skip) {
             if (in_bytes) {
                 const uint8_t *p = in_bytes + 4 * (size_t)i;
                 v = p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
@@ -408,6 +418,7 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ in_,
             total_out[0] = (uint8_t)tot; total_out[1] = (uint8_t)(tot >> 8);
             total_out[2] = (uint8_t)(tot >> 16); total_out[3] = (uint8_t)(tot >> 24);
         }
+        if (status_bytes_) status_bytes_[2 * blockIdx.y + 1] = fixed_bytes + tot;   // sicn_codec_status.bytes
     }
 }
 
@@ -480,6 +491,134 @@ __global__ __launch_bounds__(256) void k_unpack7(const uint8_t *__restrict__ in,
     for (int k = 0; k < 7; k++) v |= (unsigned long long)in[7 * (size_t)g + k] << (8 * k);
     for (int k = 0; k < 8; k++)
         if (g * 8 + k < n) lat[g * 8 + k] = (uint8_t)((v >> (7 * k)) & 127);
+}
+
+
+// ---- asynchronous batch path: everything the host did between two synchronisations, on the device -----------
+// blockIdx.y = image everywhere; per-image workspace stride s_ws, container slot stride s_slot.
+
+__global__ __launch_bounds__(64) void k_clear_stats(uint32_t *__restrict__ hist_, size_t s_ws)
+{
+    uint32_t *h = img_ptr(hist_, s_ws);   // hist[256] + sums (64 B) + freq (256 B) + meta (64 B) are contiguous
+    for (uint32_t i = threadIdx.x; i < (1024 + 64 + 256 + 64) / 4; i += 64) h[i] = 0;
+}
+
+// Histogram -> 12-bit frequencies exactly as `normalize` / sicl_or_normalize do it (same floor, same "largest first,
+// lowest index on ties" correction walk), by one wave: lane l owns symbols 2l, 2l+1.  Then the container header and
+// frequency table.  status[0] = error flags (bit 0: symbol >= 128, bit 1: normalisation failed).
+__global__ __launch_bounds__(64) void k_enc_header(const uint32_t *__restrict__ hist_, const unsigned long long *__restrict__ sums_,
+                                                   uint16_t *__restrict__ freq_, uint8_t *__restrict__ out_, uint32_t *__restrict__ status_,
+                                                   uint32_t n, uint32_t ns, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c,
+                                                   uint32_t img_w, uint32_t img_h, size_t s_ws, size_t s_slot)
+{
+    const uint32_t *hist = img_ptr(hist_, s_ws);
+    const unsigned long long *sums = img_ptr(sums_, s_ws);
+    uint16_t *freq = img_ptr(freq_, s_ws);
+    uint8_t *out = img_ptr(out_, s_slot);
+    uint32_t *status = status_ + 2 * blockIdx.y;
+    const int lane = threadIdx.x;
+    uint32_t err = 0;
+    if (hist[128 + lane] | hist[192 + lane]) err = 1;
+    uint32_t f[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const uint32_t h = hist[2 * lane + k];
+        unsigned long long v = (h && n) ? ((unsigned long long)h * 4096u) / n : 0;
+        if (h && v == 0) v = 1;
+        f[k] = (uint32_t)v;
+    }
+    int sum = (int)(f[0] + f[1]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+    int diff = n ? 4096 - sum : 0;
+    for (int it = 0; it < 200 && diff != 0; it++) {
+        // candidate of this lane: f > 0 and (diff > 0 or f > 1); key = (f << 8) | (255 - index): max key = largest f, lowest index
+        uint32_t key = 0;
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            if (f[k] > 0 && (diff > 0 || f[k] > 1)) key = max(key, (f[k] << 8) | (uint32_t)(255 - (2 * lane + k)));
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) key = max(key, (uint32_t)__shfl_xor((int)key, d));
+        if (key == 0) { err |= 2; break; }
+        const int best = 255 - (int)(key & 255u), fb = (int)(key >> 8);
+        const int step = diff > 0 ? diff : (diff < 1 - fb ? 1 - fb : diff);
+        if ((best >> 1) == lane) f[best & 1] = (uint32_t)(fb + step);
+        diff -= step;
+    }
+    if (diff != 0) err |= 2;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) err |= (uint32_t)__shfl_xor((int)err, d);
+    if (err) f[0] = f[1] = 0;   // the encode kernel skips zero-frequency symbols: it stays memory-safe
+    freq[2 * lane] = (uint16_t)f[0];
+    freq[2 * lane + 1] = (uint16_t)f[1];
+    uint8_t *ft = out + SICN_CODEC_HEADER_BYTES + 4 * lane;
+    ft[0] = (uint8_t)f[0]; ft[1] = (uint8_t)(f[0] >> 8); ft[2] = (uint8_t)f[1]; ft[3] = (uint8_t)(f[1] >> 8);
+    if (lane < 12) {   // header dwords 0..11 (dword 10 = payload bytes is written by k_scan)
+        const unsigned long long s1 = sums[0], s2 = sums[1];
+        const uint32_t a = (uint32_t)((1 + s1) % ADLER_MOD), b = (uint32_t)((n % ADLER_MOD + s2) % ADLER_MOD);
+        const uint32_t words[12] = {0x4C434953u /* "SICL" */, 1u | ((uint32_t)SICN_CODEC_RANSW << 16), img_w, img_h, lat_w, lat_h,
+                                    lat_c, n, ns, WSS, 0u, (b << 16) | a};
+        if (lane != 10) {
+            const uint32_t v = words[lane];
+            uint8_t *p = out + 4 * lane;
+            p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
+        }
+    }
+    if (lane == 0) status[0] = err;
+}
+
+// Decoder front end: every header field against the shape the caller expects, the frequency table, and the sizes
+// against the bytes the caller vouches for.  meta[0] |= error bits, meta[1] = payload bytes the streams may use.
+__global__ __launch_bounds__(64) void k_dec_parse(const uint8_t *__restrict__ containers_, const uint32_t *__restrict__ valid_bytes_,
+                                                  uint32_t valid_stride, uint32_t *__restrict__ meta_, uint32_t n, uint32_t ns,
+                                                  uint32_t lat_w, uint32_t lat_h, uint32_t lat_c, size_t s_slot, size_t s_ws)
+{
+    const uint8_t *c = img_ptr(containers_, s_slot);
+    uint32_t *meta = img_ptr(meta_, s_ws);
+    const int lane = threadIdx.x;
+    const uint32_t valid = valid_bytes_ ? min(valid_bytes_[(size_t)blockIdx.y * valid_stride], (uint32_t)min(s_slot, (size_t)0xFFFFFFFFu))
+                                        : (uint32_t)min(s_slot, (size_t)0xFFFFFFFFu);
+    const size_t fixed = SICN_CODEC_HEADER_BYTES + 256 + 4 * (size_t)ns;
+    uint32_t err = 0;
+    if (valid < fixed) {   // nothing of this slot may be read
+        if (lane == 0) { meta[0] = 0x104u; meta[1] = 0; meta[2] = 0; }
+        return;
+    }
+    auto rd32 = [&](int o) { return c[o] | ((uint32_t)c[o + 1] << 8) | ((uint32_t)c[o + 2] << 16) | ((uint32_t)c[o + 3] << 24); };
+    const uint32_t expect[10] = {0x4C434953u, 1u | ((uint32_t)SICN_CODEC_RANSW << 16), 0, 0, lat_w, lat_h, lat_c, n, ns, WSS};
+    if (lane < 10 && lane != 2 && lane != 3 && rd32(4 * lane) != expect[lane]) err = 4;
+    uint32_t fsum = c[SICN_CODEC_HEADER_BYTES + 4 * lane] + ((uint32_t)c[SICN_CODEC_HEADER_BYTES + 4 * lane + 1] << 8) +
+                    c[SICN_CODEC_HEADER_BYTES + 4 * lane + 2] + ((uint32_t)c[SICN_CODEC_HEADER_BYTES + 4 * lane + 3] << 8);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) fsum += __shfl_xor((int)fsum, d);
+    if (n && fsum != 4096) err |= 8;
+    const uint32_t pb = rd32(40);
+    if ((size_t)pb > (size_t)valid - fixed) err |= 16;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) err |= (uint32_t)__shfl_xor((int)err, d);
+    if (lane == 0) {
+        meta[0] = err;
+        meta[1] = (err & 16) ? 0u : pb;
+        meta[2] = rd32(44);
+    }
+}
+
+// Decoder back end: stream-level errors, table total, checksum -> status {error, n_symbols}.
+__global__ __launch_bounds__(64) void k_dec_finish(const uint32_t *__restrict__ meta_, const uint32_t *__restrict__ hist_,
+                                                   const unsigned long long *__restrict__ sums_, const uint32_t *__restrict__ offsets_,
+                                                   uint32_t *__restrict__ status_, uint32_t n, uint32_t ns, size_t s_ws)
+{
+    if (threadIdx.x) return;
+    const uint32_t *meta = img_ptr(meta_, s_ws), *offsets = img_ptr(offsets_, s_ws);
+    (void)hist_;
+    const unsigned long long *sums = img_ptr(sums_, s_ws);
+    uint32_t err = meta[0];
+    if (meta[3]) err |= 32;                          // a stream overran / underran (k_ransw_decode, k_scan)
+    if (offsets[ns] != meta[1]) err |= 64;           // the length table does not add up to the payload
+    const uint32_t a = (uint32_t)((1 + sums[0]) % ADLER_MOD), b = (uint32_t)((n % ADLER_MOD + sums[1]) % ADLER_MOD);
+    if (!err && ((b << 16) | a) != meta[2]) err |= 128;   // checksum (SICN_EBADMSG)
+    status_[2 * blockIdx.y] = err;
+    status_[2 * blockIdx.y + 1] = n;
 }
 
 // ---- host helpers --------------------------------------------------------------------------------
@@ -725,7 +864,7 @@ extern "C" int sicn_codec_decode(const uint8_t *container, size_t bytes, uint8_t
         if (total != info.payload_bytes) return SICN_EINVAL;
         if (ns && info.mode == SICN_CODEC_RANSW)
             hipLaunchKernelGGL(k_ransw_decode, dim3(ns), dim3(64), 0, stream, payload, freq_bytes, w.offsets, n, ns, latent, err, (size_t)0, (size_t)0, (size_t)0,
-                               container + 40);
+                               container + 40, (const uint32_t *)nullptr);
         else if (ns)
             hipLaunchKernelGGL(k_rans_decode, dim3((ns + 255) / 256), dim3(256), 0, stream, payload, freq_bytes, w.offsets, n, ns, latent, err,
                                info.payload_bytes);
@@ -745,11 +884,94 @@ extern "C" int sicn_codec_decode(const uint8_t *container, size_t bytes, uint8_t
 }
 
 
-// ---- batches: the same containers, n images per call, two host synchronisations per call instead of
-// ---- three per image (statistics -> tables on the host; sizes / verdicts back at the end) ---------------
+// ---- batches -------------------------------------------------------------------------------------------------
+// The asynchronous pair does everything on the device (statistics -> frequency table -> header -> streams -> offsets
+// -> compaction; parse -> offsets -> streams -> checksum) and reports through a device status array: no host
+// synchronisation, no allocation, capturable in a hipGraph.  The synchronous batch calls are thin wrappers that add
+// the read-back.
 extern "C" size_t sicn_codec_batch_workspace_bytes(int mode, uint32_t n_symbols, uint32_t n_images)
 {
-    return (size_t)n_images * align_up(sicn_codec_workspace_bytes(mode, n_symbols), 256);
+    // per-image blocks, then room for the synchronous wrappers' status arrays (2 x 8 bytes per image)
+    return (size_t)n_images * align_up(sicn_codec_workspace_bytes(mode, n_symbols), 256) + align_up(16 * (size_t)n_images, 256);
+}
+
+extern "C" int sicn_codec_encode_batch_async(const uint8_t *latents, uint32_t n_images, uint32_t lat_w, uint32_t lat_h,
+                                             uint32_t lat_c, uint32_t img_w, uint32_t img_h, uint8_t *out, size_t slot_bytes,
+                                             sicn_codec_status *status_dev, void *workspace, size_t workspace_bytes,
+                                             void *hip_stream)
+{
+    if (!out || !status_dev) return SICN_EINVAL;
+    const unsigned long long n64 = (unsigned long long)lat_w * lat_h * lat_c;
+    if (n64 > MAX_RANS_SYMBOLS || (n64 && !latents) || n_images > 65535) return SICN_EINVAL;
+    if (n_images == 0) return SICN_OK;
+    const uint32_t n = (uint32_t)n64, ns = (n + WSS - 1) / WSS;
+    if (slot_bytes < sicn_codec_max_bytes(SICN_CODEC_RANSW, n) || (slot_bytes & 1)) return SICN_ENOSPC;
+    const size_t ws1 = align_up(sicn_codec_workspace_bytes(SICN_CODEC_RANSW, n), 256);
+    if (!workspace || workspace_bytes < ws1 * n_images) return SICN_ENOSPC;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    Workspace w;
+    carve(w, workspace, ns, WCAP);
+    uint32_t *status = (uint32_t *)status_dev;
+    uint8_t *table = out + SICN_CODEC_HEADER_BYTES + 256, *payload = table + 4 * (size_t)ns;
+    const uint32_t fixed = (uint32_t)(SICN_CODEC_HEADER_BYTES + 256 + 4 * (size_t)ns);
+    hipLaunchKernelGGL(k_clear_stats, dim3(1, n_images), dim3(64), 0, stream, w.hist, ws1);
+    if (n)
+        hipLaunchKernelGGL(k_stats, dim3(min((n / 16 + 255u) / 256u + 1u, 128u), n_images), dim3(256), 0, stream, latents, n, w.hist,
+                           w.sums, (size_t)n, ws1);
+    hipLaunchKernelGGL(k_enc_header, dim3(1, n_images), dim3(64), 0, stream, w.hist, w.sums, w.freq, out, status, n, ns, lat_w,
+                       lat_h, lat_c, img_w, img_h, ws1, slot_bytes);
+    if (ns)
+        hipLaunchKernelGGL(k_ransw_encode, dim3(ns, n_images), dim3(64), 0, stream, latents, n, ns, w.freq, w.scratch, w.lens,
+                           (size_t)n, ws1);
+    hipLaunchKernelGGL(k_scan, dim3(1, n_images), dim3(1024), 0, stream, w.lens, (const uint8_t *)nullptr, ns, w.offsets, table,
+                       out + 40, ws1, slot_bytes, 0xFFFFFFFFu, (uint32_t *)nullptr, status, fixed);
+    if (ns)
+        hipLaunchKernelGGL(k_compact, dim3(ns, n_images), dim3(256), 0, stream, w.scratch, w.lens, w.offsets, payload, WCAP, ws1,
+                           slot_bytes);
+    return hipGetLastError() == hipSuccess ? SICN_OK : SICN_ENODEV;
+}
+
+extern "C" int sicn_codec_decode_batch_async(const uint8_t *containers, size_t slot_bytes, const sicn_codec_status *valid_dev_or_null,
+                                             uint32_t n_images, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c, uint8_t *latents,
+                                             size_t latent_stride, sicn_codec_status *status_dev, void *workspace,
+                                             size_t workspace_bytes, void *hip_stream)
+{
+    if (!containers || !status_dev || (slot_bytes & 1)) return SICN_EINVAL;
+    const unsigned long long n64 = (unsigned long long)lat_w * lat_h * lat_c;
+    if (n64 > MAX_RANS_SYMBOLS || n_images > 65535) return SICN_EINVAL;
+    if (n_images == 0) return SICN_OK;
+    const uint32_t n = (uint32_t)n64, ns = (n + WSS - 1) / WSS;
+    if (n && (!latents || latent_stride < n)) return SICN_ENOSPC;
+    const size_t ws1 = align_up(sicn_codec_workspace_bytes(SICN_CODEC_RANSW, n), 256);
+    if (!workspace || workspace_bytes < ws1 * n_images) return SICN_ENOSPC;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    Workspace w;
+    carve(w, workspace, ns, 0);
+    const uint8_t *freq_bytes = containers + SICN_CODEC_HEADER_BYTES, *table = freq_bytes + 256, *payload = table + 4 * (size_t)ns;
+    hipLaunchKernelGGL(k_clear_stats, dim3(1, n_images), dim3(64), 0, stream, w.hist, ws1);
+    hipLaunchKernelGGL(k_dec_parse, dim3(1, n_images), dim3(64), 0, stream, containers,
+                       valid_dev_or_null ? &valid_dev_or_null->bytes : (const uint32_t *)nullptr, 2u, w.meta, n, ns, lat_w, lat_h,
+                       lat_c, slot_bytes, ws1);
+    // a slot the parse stage rejected as too short is never read: its table counts as empty (ns_eff = 0 via meta[1] = 0 and
+    // the per-stream bound off + len <= payload bytes, so every stream of it flags an error and returns)
+    hipLaunchKernelGGL(k_scan, dim3(1, n_images), dim3(1024), 0, stream, (const uint32_t *)nullptr, table, ns, w.offsets,
+                       (uint8_t *)nullptr, (uint8_t *)nullptr, ws1, slot_bytes, WCAP, w.meta + 3, (uint32_t *)nullptr, 0u,
+                       (const uint32_t *)w.meta);
+    if (ns)
+        hipLaunchKernelGGL(k_ransw_decode, dim3(ns, n_images), dim3(64), 0, stream, payload, freq_bytes, w.offsets, n, ns, latents,
+                           w.meta + 3, slot_bytes, ws1, latent_stride, containers + 40, w.meta);
+    if (n)
+        hipLaunchKernelGGL(k_stats, dim3(min((n / 16 + 255u) / 256u + 1u, 128u), n_images), dim3(256), 0, stream, latents, n, w.hist,
+                           w.sums, latent_stride, ws1);
+    hipLaunchKernelGGL(k_dec_finish, dim3(1, n_images), dim3(64), 0, stream, w.meta, w.hist, w.sums, w.offsets, (uint32_t *)status_dev,
+                       n, ns, ws1);
+    return hipGetLastError() == hipSuccess ? SICN_OK : SICN_ENODEV;
+}
+
+static int status_to_rc(uint32_t err)
+{
+    if (!err) return SICN_OK;
+    return (err & ~128u) ? SICN_EINVAL : SICN_EBADMSG;
 }
 
 extern "C" int sicn_codec_encode_batch(int mode, const uint8_t *latents, uint32_t n_images, uint32_t lat_w, uint32_t lat_h,
@@ -757,81 +979,26 @@ extern "C" int sicn_codec_encode_batch(int mode, const uint8_t *latents, uint32_
                                        size_t *out_bytes_host, void *workspace, size_t workspace_bytes, void *hip_stream)
 {
     if (mode != SICN_CODEC_RANSW || !out || !out_bytes_host) return SICN_EINVAL;
-    const unsigned long long n64 = (unsigned long long)lat_w * lat_h * lat_c;
-    if (n64 > MAX_RANS_SYMBOLS || (n64 && !latents)) return SICN_EINVAL;
     if (n_images == 0) return SICN_OK;
-    const uint32_t n = (uint32_t)n64, ns = (n + WSS - 1) / WSS;
-    if (slot_bytes < sicn_codec_max_bytes(mode, n) || (slot_bytes & 1)) return SICN_ENOSPC;
-    const size_t ws1 = align_up(sicn_codec_workspace_bytes(mode, n), 256);
-    if (!workspace || workspace_bytes < ws1 * n_images) return SICN_ENOSPC;
+    // the status array lives behind the per-image blocks of the caller's workspace (sicn_codec_batch_workspace_bytes)
+    const unsigned long long n64 = (unsigned long long)lat_w * lat_h * lat_c;
+    if (n64 > MAX_RANS_SYMBOLS) return SICN_EINVAL;
+    const size_t blocks = (size_t)n_images * align_up(sicn_codec_workspace_bytes(mode, (uint32_t)n64), 256);
+    if (!workspace || workspace_bytes < sicn_codec_batch_workspace_bytes(mode, (uint32_t)n64, n_images)) return SICN_ENOSPC;
     hipStream_t stream = (hipStream_t)hip_stream;
-    std::vector<Workspace> w;
-    std::vector<uint32_t> hist;
-    std::vector<unsigned long long> sums;
-    std::vector<uint8_t> head;
-    std::vector<uint16_t> freq;
-    std::vector<uint32_t> payload_bytes;
-    try {
-        w.resize(n_images);
-        hist.resize((size_t)n_images * 256);
-        sums.resize((size_t)n_images * 2);
-        head.assign((size_t)n_images * (SICN_CODEC_HEADER_BYTES + 256), 0);
-        freq.assign((size_t)n_images * 128, 0);
-        payload_bytes.assign(n_images, 0);
-    } catch (const std::bad_alloc &) { return SICN_ENOMEM; }
+    sicn_codec_status *st_dev = (sicn_codec_status *)((uint8_t *)workspace + blocks);
+    std::vector<sicn_codec_status> st;
+    try { st.resize(n_images); } catch (const std::bad_alloc &) { return SICN_ENOMEM; }
+    int rc = sicn_codec_encode_batch_async(latents, n_images, lat_w, lat_h, lat_c, img_w, img_h, out, slot_bytes, st_dev, workspace,
+                                           workspace_bytes, hip_stream);
+    if (rc == SICN_OK && hipMemcpyAsync(st.data(), st_dev, sizeof(sicn_codec_status) * n_images, hipMemcpyDeviceToHost, stream) != hipSuccess)
+        rc = SICN_ENODEV;
+    if (hipStreamSynchronize(stream) != hipSuccess) return SICN_ENODEV;
+    if (rc) return rc;
     for (uint32_t i = 0; i < n_images; i++) {
-        carve(w[i], (uint8_t *)workspace + i * ws1, ns, WCAP);
-        HIP_TRY(hipMemsetAsync(w[i].hist, 0, 1024 + 64, stream));
+        if (st[i].error) return SICN_EINVAL;
+        out_bytes_host[i] = st[i].bytes;
     }
-    // one launch per stage for the whole batch (blockIdx.y = image): the images' streams run side by side
-    if (n)
-        hipLaunchKernelGGL(k_stats, dim3(min((n / 16 + 255u) / 256u + 1u, 128u), n_images), dim3(256), 0, stream, latents, n,
-                           w[0].hist, w[0].sums, (size_t)n, ws1);
-    for (uint32_t i = 0; i < n_images; i++) {
-        HIP_TRY(hipMemcpyAsync(&hist[(size_t)i * 256], w[i].hist, 1024, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(&sums[(size_t)i * 2], w[i].sums, 16, hipMemcpyDeviceToHost, stream));
-    }
-    HIP_TRY(hipStreamSynchronize(stream));
-    for (uint32_t i = 0; i < n_images; i++) {
-        const uint32_t *h = &hist[(size_t)i * 256];
-        for (int s = 128; s < 256; s++)
-            if (h[s]) return SICN_EINVAL;
-        uint8_t *hd = &head[(size_t)i * (SICN_CODEC_HEADER_BYTES + 256)];
-        std::memcpy(hd, "SICL", 4);
-        put16(hd + 4, 1);
-        put16(hd + 6, (uint32_t)mode);
-        put32(hd + 8, img_w);
-        put32(hd + 12, img_h);
-        put32(hd + 16, lat_w);
-        put32(hd + 20, lat_h);
-        put32(hd + 24, lat_c);
-        put32(hd + 28, n);
-        put32(hd + 32, ns);
-        put32(hd + 36, WSS);
-        put32(hd + 44, adler_from_sums(sums[(size_t)i * 2], sums[(size_t)i * 2 + 1], n));
-        uint16_t *f = &freq[(size_t)i * 128];
-        if (n && !normalize(h, n, f)) return SICN_EINVAL;
-        for (int s = 0; s < 128; s++) put16(hd + SICN_CODEC_HEADER_BYTES + 2 * s, f[s]);
-        uint8_t *o = out + (size_t)i * slot_bytes;
-        HIP_TRY(hipMemcpyAsync(o, hd, SICN_CODEC_HEADER_BYTES + 256, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(w[i].freq, f, 256, hipMemcpyHostToDevice, stream));
-    }
-    {
-        uint8_t *table = out + SICN_CODEC_HEADER_BYTES + 256, *payload = table + 4 * (size_t)ns;
-        if (ns)
-            hipLaunchKernelGGL(k_ransw_encode, dim3(ns, n_images), dim3(64), 0, stream, latents, n, ns, w[0].freq, w[0].scratch,
-                               w[0].lens, (size_t)n, ws1);
-        hipLaunchKernelGGL(k_scan, dim3(1, n_images), dim3(1024), 0, stream, w[0].lens, (const uint8_t *)nullptr, ns, w[0].offsets,
-                           table, out + 40, ws1, slot_bytes, 0xFFFFFFFFu, (uint32_t *)nullptr);
-        if (ns)
-            hipLaunchKernelGGL(k_compact, dim3(ns, n_images), dim3(256), 0, stream, w[0].scratch, w[0].lens, w[0].offsets, payload,
-                               WCAP, ws1, slot_bytes);
-    }
-    for (uint32_t i = 0; i < n_images; i++)
-        HIP_TRY(hipMemcpyAsync(&payload_bytes[i], w[i].offsets + ns, 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    if (hipGetLastError() != hipSuccess) return SICN_ENODEV;
-    for (uint32_t i = 0; i < n_images; i++) out_bytes_host[i] = SICN_CODEC_HEADER_BYTES + 256 + 4 * (size_t)ns + payload_bytes[i];
     return SICN_OK;
 }
 
@@ -844,68 +1011,43 @@ extern "C" int sicn_codec_decode_batch(const uint8_t *containers, size_t slot_by
     hipStream_t stream = (hipStream_t)hip_stream;
     std::vector<uint8_t> head;
     std::vector<sicn_codec_info> info;
-    std::vector<Workspace> w;
-    std::vector<uint32_t> flag, total;
-    std::vector<unsigned long long> sums;
+    std::vector<sicn_codec_status> st;
     try {
-        head.resize((size_t)n_images * (SICN_CODEC_HEADER_BYTES + 256));
+        head.resize((size_t)n_images * SICN_CODEC_HEADER_BYTES);
         info.resize(n_images);
-        w.resize(n_images);
-        flag.assign(n_images, 0);
-        total.assign(n_images, 0);
-        sums.assign((size_t)n_images * 2, 0);
+        st.resize(2 * (size_t)n_images);
     } catch (const std::bad_alloc &) { return SICN_ENOMEM; }
-    const size_t hb = SICN_CODEC_HEADER_BYTES + 256;
+    // first synchronisation: the shape comes out of the containers (the async entry point takes it from the caller)
     for (uint32_t i = 0; i < n_images; i++) {
-        if (bytes_host[i] < hb || bytes_host[i] > slot_bytes) return SICN_EINVAL;
-        HIP_TRY(hipMemcpyAsync(&head[i * hb], containers + (size_t)i * slot_bytes, hb, hipMemcpyDeviceToHost, stream));
+        if (bytes_host[i] < SICN_CODEC_HEADER_BYTES + 256 || bytes_host[i] > slot_bytes) return SICN_EINVAL;
+        HIP_TRY(hipMemcpyAsync(&head[(size_t)i * SICN_CODEC_HEADER_BYTES], containers + (size_t)i * slot_bytes, SICN_CODEC_HEADER_BYTES,
+                               hipMemcpyDeviceToHost, stream));
     }
     HIP_TRY(hipStreamSynchronize(stream));
-    size_t ws1 = 0;
     for (uint32_t i = 0; i < n_images; i++) {
-        int rc = sicn_codec_parse_header(&head[i * hb], SICN_CODEC_HEADER_BYTES, &info[i]);
+        int rc = sicn_codec_parse_header(&head[(size_t)i * SICN_CODEC_HEADER_BYTES], SICN_CODEC_HEADER_BYTES, &info[i]);
         if (rc) return rc;
         if (info[i].mode != SICN_CODEC_RANSW) return SICN_EINVAL;
-        if (info[i].n_symbols != info[0].n_symbols || info[i].n_symbols > MAX_RANS_SYMBOLS) return SICN_EINVAL;
-        if (info[i].n_symbols && (!latents || latent_stride < info[i].n_symbols)) return SICN_ENOSPC;
-        const size_t fixed = hb + 4 * (size_t)info[i].n_streams;
-        if (bytes_host[i] < fixed + info[i].payload_bytes) return SICN_EINVAL;
-        uint32_t sum = 0;
-        for (int s = 0; s < 128; s++) sum += get16(&head[i * hb + SICN_CODEC_HEADER_BYTES + 2 * s]);
-        if (info[i].n_symbols && sum != 4096) return SICN_EINVAL;
+        if (info[i].lat_w != info[0].lat_w || info[i].lat_h != info[0].lat_h || info[i].lat_c != info[0].lat_c) return SICN_EINVAL;
+        if (info[i].n_symbols > MAX_RANS_SYMBOLS) return SICN_EINVAL;
         if (infos_or_null) infos_or_null[i] = info[i];
+        st[i].error = 0;
+        st[i].bytes = (uint32_t)bytes_host[i];
     }
-    const uint32_t n = info[0].n_symbols, ns = info[0].n_streams;
-    ws1 = align_up(sicn_codec_workspace_bytes(SICN_CODEC_RANSW, n), 256);
-    if (!workspace || workspace_bytes < ws1 * n_images) return SICN_ENOSPC;
-    for (uint32_t i = 0; i < n_images; i++) {
-        carve(w[i], (uint8_t *)workspace + i * ws1, ns, 0);
-        HIP_TRY(hipMemsetAsync(w[i].hist, 0, 1024 + 64, stream));
-    }
-    {   // one launch per stage for the whole batch (blockIdx.y = image)
-        const uint8_t *freq_bytes = containers + SICN_CODEC_HEADER_BYTES, *table = freq_bytes + 256, *payload = table + 4 * (size_t)ns;
-        hipLaunchKernelGGL(k_scan, dim3(1, n_images), dim3(1024), 0, stream, (const uint32_t *)nullptr, table, ns, w[0].offsets,
-                           (uint8_t *)nullptr, (uint8_t *)nullptr, ws1, slot_bytes, WCAP, w[0].hist + 255);
-        if (ns)
-            hipLaunchKernelGGL(k_ransw_decode, dim3(ns, n_images), dim3(64), 0, stream, payload, freq_bytes, w[0].offsets, n, ns,
-                               latents, w[0].hist + 255, slot_bytes, ws1, latent_stride, containers + 40);
-    }
-    for (uint32_t i = 0; i < n_images; i++) {
-        HIP_TRY(hipMemcpyAsync(&total[i], w[i].offsets + ns, 4, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(&flag[i], w[i].hist + 255, 4, hipMemcpyDeviceToHost, stream));
-    }
-    // checksums (the flags were read back in stream order before the statistics block is reused)
-    for (uint32_t i = 0; i < n_images; i++) HIP_TRY(hipMemsetAsync(w[i].hist, 0, 1024 + 64, stream));
-    if (n)
-        hipLaunchKernelGGL(k_stats, dim3(min((n / 16 + 255u) / 256u + 1u, 128u), n_images), dim3(256), 0, stream, latents, n,
-                           w[0].hist, w[0].sums, latent_stride, ws1);
+    const size_t blocks = (size_t)n_images * align_up(sicn_codec_workspace_bytes(SICN_CODEC_RANSW, info[0].n_symbols), 256);
+    if (!workspace || workspace_bytes < sicn_codec_batch_workspace_bytes(SICN_CODEC_RANSW, info[0].n_symbols, n_images)) return SICN_ENOSPC;
+    sicn_codec_status *st_dev = (sicn_codec_status *)((uint8_t *)workspace + blocks);   // [0, n): valid bytes in, [n, 2n): verdicts out
+    int rc = hipMemcpyAsync(st_dev, st.data(), sizeof(sicn_codec_status) * n_images, hipMemcpyHostToDevice, stream) == hipSuccess
+                 ? SICN_OK : SICN_ENODEV;
+    if (rc == SICN_OK)
+        rc = sicn_codec_decode_batch_async(containers, slot_bytes, st_dev, n_images, info[0].lat_w, info[0].lat_h, info[0].lat_c, latents,
+                                           latent_stride, st_dev + n_images, workspace, workspace_bytes, hip_stream);
+    if (rc == SICN_OK && hipMemcpyAsync(st.data() + n_images, st_dev + n_images, sizeof(sicn_codec_status) * n_images,
+                                        hipMemcpyDeviceToHost, stream) != hipSuccess)
+        rc = SICN_ENODEV;
+    if (hipStreamSynchronize(stream) != hipSuccess) return SICN_ENODEV;
+    if (rc) return rc;
     for (uint32_t i = 0; i < n_images; i++)
-        HIP_TRY(hipMemcpyAsync(&sums[(size_t)i * 2], w[i].sums, 16, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    if (hipGetLastError() != hipSuccess) return SICN_ENODEV;
-    for (uint32_t i = 0; i < n_images; i++) {
-        if (flag[i] || total[i] != info[i].payload_bytes) return SICN_EINVAL;
-        if (adler_from_sums(sums[(size_t)i * 2], sums[(size_t)i * 2 + 1], n) != info[i].adler32) return SICN_EBADMSG;
-    }
+        if (int e = status_to_rc(st[n_images + i].error)) return e;
     return SICN_OK;
 }

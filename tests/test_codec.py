@@ -281,3 +281,121 @@ def test_gpu_batch_equals_single_calls_and_oracle():
     with pytest.raises(_lib.SicnError) as e:
         codec.decode_latents(bad, sizes)
     assert e.value.code in (-22, -74)
+
+
+@gpu
+def test_gpu_async_pair_equals_sync_and_oracle():
+    """sicn_codec_encode_batch_async / decode_batch_async: device-side statistics -> normalisation -> header; containers
+    byte-identical to the synchronous calls and to the oracle on distributions that stress the normalisation walk
+    (many rare symbols: the sum of floors overshoots 4096 and several entries are corrected), sizes and verdicts in
+    device memory, decode round trip exact."""
+    import torch
+    from simple_image_compression_network_amd import codec
+    rng = np.random.default_rng(77)
+    shape = (9, 10, 192)
+    n = int(np.prod(shape))
+    lats = [_mock_latent(rng, shape, zero_frac=z) for z in (0.5, 0.0, 1.0)]
+    # many rare symbols: 127 symbols appear 1-3 times each beside one dominant -> every rare v == 0 is bumped to 1
+    rare = np.zeros(n, np.uint8)
+    idx = rng.choice(n, 250, replace=False)
+    rare[idx] = rng.integers(1, 128, 250)
+    lats.append(rare.reshape(shape))
+    lats.append(_skewed_latent(rng, n, 0.9313).reshape(shape))
+    lat = np.stack(lats)
+    dev = torch.from_numpy(lat).cuda()
+    coder = codec.LatentCoder(lat.shape[0], *shape, image_width=160, image_height=144)
+    coder.encode(dev)
+    back = torch.empty_like(dev)
+    coder.decode(back)
+    coder.check()
+    sizes = coder.sizes()
+    for i in range(lat.shape[0]):
+        blob = coder.slots[i, :sizes[i]].cpu().numpy().tobytes()
+        assert blob == c_oracle.codec_encode(lat[i], (160, 144), 3), i
+    assert torch.equal(back, dev)
+    # the synchronous wrappers give the same bytes
+    slots, sz = codec.encode_latents(dev, 160, 144)
+    assert sz == sizes and all(torch.equal(slots[i, :sz[i]], coder.slots[i, :sz[i]]) for i in range(len(sz)))
+
+
+@gpu
+def test_gpu_async_reports_errors_in_device_status():
+    import torch
+    from simple_image_compression_network_amd import _lib, codec
+    rng = np.random.default_rng(78)
+    shape = (9, 10, 192)
+    lat = np.stack([_mock_latent(rng, shape) for _ in range(3)])
+    dev = torch.from_numpy(lat).cuda()
+    coder = codec.LatentCoder(3, *shape)
+    bad = dev.clone()
+    bad[1, 0, 0, 0] = 200                                     # symbol >= 128 in image 1 only
+    coder.encode(bad)
+    st = coder.enc_status.cpu().numpy()
+    assert st[1, 0] & 1 and st[0, 0] == 0 and st[2, 0] == 0
+    coder.encode(dev)
+    assert not coder.enc_status[:, 0].any()
+    sizes = coder.sizes()
+    back = torch.empty_like(dev)
+    good = coder.slots.clone()
+    # payload bit flip -> stream error or checksum; header shape mismatch; frequency table sum; hostile table; short slot
+    cases = []
+    c = good.clone(); c[0, sizes[0] - 3] ^= 0x04; cases.append((c, None, 0))
+    c = good.clone(); c[2, 16] ^= 0x01; cases.append((c, None, 2))                 # lat_w field
+    c = good.clone(); c[1, 48 + 7] ^= 0x01; cases.append((c, None, 1))             # a frequency
+    tab = 48 + 256
+    c = good.clone(); c[1, tab:tab + 4] = torch.tensor([0, 0, 255, 255], dtype=torch.uint8).cuda(); cases.append((c, None, 1))
+    short = coder.enc_status.clone(); short[2, 1] = 100; cases.append((good.clone(), short, 2))
+    for slots, valid, which in cases:
+        coder.decode(back, slots=slots, valid=valid)
+        st = coder.dec_status.cpu().numpy()
+        assert st[which, 0] != 0, (which, st)
+        assert all(st[k, 0] == 0 for k in range(3) if k != which), st
+        with pytest.raises(_lib.SicnError):
+            coder.check()
+    coder.decode(back, slots=good)
+    coder.check()
+    assert torch.equal(back, dev)
+
+
+@gpu
+def test_gpu_coded_pipeline_is_graph_capturable():
+    """analysis -> encode -> decode -> synthesis as ONE hipGraph: none of the four stages allocates or synchronises."""
+    import gc
+    import torch
+    from simple_image_compression_network_amd import api, codec
+    net = api.EightLayersNet(256, 256)
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.integers(0, 256, (2, 256, 256, 3), dtype=np.uint8)).cuda()
+    lat, lat2 = (torch.empty((2, 16, 16, 192), dtype=torch.uint8, device="cuda") for _ in range(2))
+    out = torch.empty((2, 256, 256, 3), dtype=torch.uint8, device="cuda")
+    coder = codec.LatentCoder(2, 16, 16, 192, 256, 256)
+
+    def pipeline():
+        net.analysis(x, lat)
+        coder.encode(lat)
+        coder.decode(lat2)
+        net.synthesis(lat2, out)
+
+    pipeline()
+    coder.check()
+    ref_out, _ = net.forward(x)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref_out)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                pipeline()
+    finally:
+        gc.enable()
+    x.copy_(torch.from_numpy(rng.integers(0, 256, (2, 256, 256, 3), dtype=np.uint8)).cuda())
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    coder.check()
+    ref_out, ref_lat = net.forward(x)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref_out) and torch.equal(lat2, ref_lat)
