@@ -21,8 +21,8 @@ class OrDesc(ctypes.Structure):
 
 def build(force: bool = False) -> Path:
     so = _HERE / "libsicn_oracle.so"
-    src = _HERE / "sicn_oracle.c"
-    if force or not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+    srcs = [_HERE / n for n in ("sicn_oracle.c", "sicn_codec_oracle.c", "sicn_gdn_oracle.c")]
+    if force or not so.exists() or so.stat().st_mtime < max(f.stat().st_mtime for f in srcs):
         subprocess.run(["make", "-C", str(_HERE), "-B", "libsicn_oracle.so"], check=True,
                        capture_output=True)
     return so
@@ -41,6 +41,10 @@ def lib() -> ctypes.CDLL:
             getattr(L, name).restype = ctypes.c_int
         L.sicn_or_layer_direct.argtypes = [ctypes.POINTER(OrDesc), p, p, p, p, ctypes.c_int]
         L.sicn_or_layer_direct.restype = ctypes.c_int
+        L.sicn_or_layer_direct_act.argtypes = [ctypes.POINTER(OrDesc), p, p, p, p, ctypes.c_int, ctypes.c_int]
+        L.sicn_or_layer_direct_act.restype = ctypes.c_int
+        L.sicn_or_gdn.argtypes = [p, p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, p, p]
+        L.sicn_or_gdn.restype = ctypes.c_int
         L.sicn_or_swg_nonsquare_fsm.argtypes = [p, ctypes.c_longlong, p] + [ctypes.c_int] * 10
         L.sicn_or_swg_nonsquare_fsm.restype = ctypes.c_longlong
         L.sicn_or_im2col_s1.argtypes = [p, p] + [ctypes.c_int] * 5
@@ -119,6 +123,34 @@ def run_layer(d, words: np.ndarray, bias: np.ndarray, x: np.ndarray, form: str =
         raise ValueError(form)
     if rc != 0:
         raise RuntimeError(f"oracle {form} failed rc={rc}")
+    return out
+
+
+def run_layer_preact(d, words: np.ndarray, bias: np.ndarray, x: np.ndarray, threads: int = 1) -> np.ndarray:
+    """The layer's lanes BEFORE the sign-bit ReLU (conv_nonsquare_top.cpp:272 without :273-275): input of the GDN extension."""
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    bias = np.ascontiguousarray(bias, dtype=np.int8)
+    x = np.ascontiguousarray(x, dtype=np.uint8)
+    assert x.shape == (d.IFM_COL, d.IFM_ROW, d.IFM_CH), (x.shape, d)
+    out = np.empty((d.OFM_COL, d.OFM_ROW, d.OFM_CH), dtype=np.uint8)
+    cd = _desc(d)
+    rc = lib().sicn_or_layer_direct_act(ctypes.byref(cd), _ptr(words), _ptr(bias), _ptr(x), _ptr(out), threads, 0)
+    if rc != 0:
+        raise RuntimeError(f"oracle direct_act failed rc={rc}")
+    return out
+
+
+def gdn(lanes: np.ndarray, beta: np.ndarray, gamma: np.ndarray, inverse: bool, shift: int) -> np.ndarray:
+    """oracle/sicn_gdn_oracle.c: fixed-point GDN / IGDN over [...][C] pre-activation lanes (parity unpinned)."""
+    lanes = np.ascontiguousarray(lanes, dtype=np.uint8)
+    c = lanes.shape[-1]
+    beta = np.ascontiguousarray(beta, dtype=np.uint32)
+    gamma = np.ascontiguousarray(gamma, dtype=np.uint8)
+    assert beta.shape == (c,) and gamma.shape == (c, c)
+    out = np.empty_like(lanes)
+    rc = lib().sicn_or_gdn(_ptr(lanes), _ptr(out), lanes.size // c, c, int(bool(inverse)), int(shift), _ptr(beta), _ptr(gamma))
+    if rc != 0:
+        raise RuntimeError(f"sicn_or_gdn rc={rc}")
     return out
 
 

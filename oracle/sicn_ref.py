@@ -4,13 +4,12 @@ reference's conv/deconv transform path.
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
 module; the product path (`simple_image_compression_network_amd/`) never does.
 
-Pinning status: the reference itself cannot be built here (it needs Xilinx Vivado-HLS 2020.1
-headers `ap_int.h` / `hls_stream.h` / `ap_axi_sdata.h`, README:5, which are neither vendored nor
-installed, and no stand-ins are written).  This restatement is pinned against the 24 SHA-256
-known-answer vectors of SURVEY.md Appendix A (all 8 layer outputs for three inputs, produced by
-the reference's own `conv2d<>` / `deconv522<>` templates during the survey) — see
-tests/test_oracle_golden.py — and against the reference's own self-check logic (dataflow ==
-naive golden, conv3_nonsquare_tb.cpp:1068-1104), restated in oracle/sicn_oracle.c.
+Pinning status: PINNED by reference code.  The reference's own golden convolution `conv_nonsquare<>`
+(conv.hpp:91-123) compiles here as it stands (oracle/ref_harness.cpp -> oracle/_ref, `make -C oracle ref`);
+tests/golden/make_ref_conv_vectors.py ran it on seeded random layers and over the whole net with the PARAM
+tables, and tests/test_oracle_golden.py holds this module to those bytes (tests/golden/ref_conv_vectors.npz,
+ref_conv_hashes.json — the latter reproduces all 24 hashes of SURVEY.md Appendix A).  The dataflow templates
+(conv_nonsquare_top.cpp) need Vivado-HLS headers and were not built; no stand-in header was written.
 
 Each function cites the reference lines it follows.  Tensors are row-major `[H][W][C] uint8`
 (byte-identical to the reference's `hls::stream<ap_uint<C*8>>`, channel c in bits [8c,8c+8),
@@ -118,6 +117,33 @@ def deconv522_ref(x: np.ndarray, w: np.ndarray, bias: np.ndarray) -> np.ndarray:
     padded map, kernel NOT flipped; out is 2H x 2W."""
     h, wd, _ = x.shape
     return _bias_relu_wrap8(_conv_taps(zero_stuff_pad(x), w, 2 * h, 2 * wd, 1), bias)
+
+
+def layer_preact_ref(x: np.ndarray, w: np.ndarray, bias: np.ndarray, transposed: int) -> np.ndarray:
+    """The layer's 8-bit lanes after the bias add, BEFORE the sign-bit ReLU (conv_nonsquare_top.cpp:272)."""
+    h, wd, _ = x.shape
+    if transposed:
+        acc = _conv_taps(zero_stuff_pad(x), w, 2 * h, 2 * wd, 1)
+    else:
+        acc = _conv_taps(np.pad(x, ((2, 2), (2, 2), (0, 0))), w, (h + 1) // 2, (wd + 1) // 2, 2)
+    return ((acc + bias.astype(np.int64)[None, None, :]) & 0xFF).astype(np.uint8)
+
+
+def gdn_ref(lanes: np.ndarray, beta: np.ndarray, gamma: np.ndarray, inverse: bool, shift: int) -> np.ndarray:
+    """Second, independent statement of the fixed-point GDN / IGDN of oracle/sicn_gdn_oracle.c (parity unpinned —
+    the reference has no GDN): exact Python-integer square roots (math.isqrt) instead of the C file's bisection.
+        x = max(int8(v), -127); n_i = beta_i + sum_j gamma[i][j] x_j^2
+        GDN : r = isqrt(2^32 // n)  (= max{r : r^2 n <= 2^32});   IGDN: r = isqrt(n << 16)
+        y = clamp((x r + 2^(shift-1)) >> shift, -128, 127) mod 256"""
+    import math
+    c = lanes.shape[-1]
+    x = np.maximum(lanes.reshape(-1, c).view(np.int8).astype(np.int64), -127)
+    n = beta.astype(np.int64)[None, :] + (x * x) @ gamma.astype(np.int64).T
+    flat = n.reshape(-1)
+    r = np.fromiter((math.isqrt(int(v) << 16) if inverse else math.isqrt((1 << 32) // int(v)) for v in flat), dtype=np.int64,
+                    count=flat.size).reshape(n.shape)
+    t = (x * r + (1 << (shift - 1))) >> shift
+    return (np.clip(t, -128, 127) & 0xFF).astype(np.uint8).reshape(lanes.shape)
 
 
 Params = Sequence[Tuple[np.ndarray, np.ndarray, int]]   # (W[o][ky][kx][c], bias[o], transposed)

@@ -81,6 +81,16 @@ CONVLAYER_ABI = {
     "sicn_conv_layer_batch_kernel": (_i, [_cldp, _vp, _vp, _vp, _i, _i, _vp]),
 }
 
+# include/sicn_gdn.h (extension beyond the reference: fixed-point GDN / IGDN in place of the ReLU)
+GDN_ABI = {
+    "sicn_gdn_create": (_i, [_i, _i, _i, _vp, _vp, ctypes.POINTER(_vp)]),
+    "sicn_gdn_free": (None, [_vp]),
+    "sicn_gdn_apply": (_i, [_vp, _vp, ctypes.c_longlong, _vp]),
+    "sicn_conv2d_gdn": (_i, [_descp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(COptions), _vp]),
+    "sicn_deconv522_gdn": (_i, [_descp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(COptions), _vp]),
+    "sicn_net_create_gdn": (_i, [_descp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, ctypes.POINTER(COptions), ctypes.POINTER(_vp)]),
+}
+
 _u32 = ctypes.c_uint32
 # include/sicn_codec.h (extension beyond the reference: latent container + rANS coder)
 CODEC_ABI = {
@@ -122,7 +132,7 @@ def lib() -> ctypes.CDLL:
         except ImportError:      # symbol checks etc. work without it
             pass
         L = ctypes.CDLL(str(LIB_PATH))
-        for name, (res, args) in {**ABI, **CODEC_ABI, **CONVLAYER_ABI}.items():
+        for name, (res, args) in {**ABI, **CODEC_ABI, **CONVLAYER_ABI, **GDN_ABI}.items():
             fn = getattr(L, name)          # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args

@@ -27,7 +27,7 @@ from . import _lib
 from .config import CLayerDesc, LayerDesc, REFERENCE_DESCS, eight_layer_descs
 
 __all__ = ["FixedPointWeights", "DeviceWeights", "conv2d", "deconv522", "conv2d_layer0", "deconv2d_layer4",
-           "eight_layers_net", "EightLayersNet", "load_param_weights", "PARAM"]
+           "eight_layers_net", "EightLayersNet", "load_param_weights", "PARAM", "GDN"]
 
 _DATA = Path(__file__).resolve().parent / "data" / "param_weights.npz"
 
@@ -93,6 +93,45 @@ class DeviceWeights:
             pass
 
 
+class GDN:
+    """Fixed-point GDN (inverse=False) / IGDN (inverse=True) activation, include/sicn_gdn.h.  EXTENSION BEYOND THE
+    REFERENCE (it has no GDN, activations.hpp:127-224); replaces a layer's sign-bit ReLU (conv_nonsquare_top.cpp:273-275).
+    beta: uint32 [C] in [1, 65535]; gamma: uint8 [C][C] in [0, 127]; shift in [1, 24]."""
+
+    def __init__(self, beta, gamma, inverse: bool = False, shift: int = 12):
+        beta = np.ascontiguousarray(beta, dtype=np.uint32)
+        gamma = np.ascontiguousarray(gamma, dtype=np.uint8)
+        c = int(beta.shape[0])
+        if gamma.shape != (c, c):
+            raise ValueError("gamma must be [C][C]")
+        self.channels, self.inverse, self.shift = c, bool(inverse), int(shift)
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.lib().sicn_gdn_create(c, int(self.inverse), self.shift, beta.ctypes.data_as(ctypes.c_void_p),
+                                              gamma.ctypes.data_as(ctypes.c_void_p), ctypes.byref(self._h)), "sicn_gdn_create")
+
+    @property
+    def handle(self) -> ctypes.c_void_p:
+        return self._h
+
+    def apply_(self, lanes, stream=None):
+        """In place over a contiguous CUDA uint8 tensor [...][C] of pre-activation lanes."""
+        import torch
+        if not (isinstance(lanes, torch.Tensor) and lanes.is_cuda and lanes.dtype == torch.uint8 and lanes.is_contiguous()
+                and lanes.shape[-1] == self.channels):
+            raise TypeError("lanes: need a contiguous CUDA uint8 tensor [...][C]")
+        _lib.check(_lib.lib().sicn_gdn_apply(self._h, ctypes.c_void_p(lanes.data_ptr()), lanes.numel() // self.channels,
+                                             _stream_ptr(stream)), "sicn_gdn_apply")
+        return lanes
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and _lib._lib is not None:
+                _lib._lib.sicn_gdn_free(self._h)
+                self._h = None
+        except Exception:       # interpreter shutdown
+            pass
+
+
 def _as_device(desc, weights, bias) -> DeviceWeights:
     return weights if isinstance(weights, DeviceWeights) else DeviceWeights(desc, weights, bias)
 
@@ -106,7 +145,7 @@ def _opt_ptr(options):
     return ctypes.byref(options)
 
 
-def _run(fn_name, desc, weights, bias, in_, out, numReps, stream, options=None):
+def _run(fn_name, desc, weights, bias, in_, out, numReps, stream, options=None, gdn=None):
     import torch
     L = _lib.lib()
     desc.validate()
@@ -116,21 +155,27 @@ def _run(fn_name, desc, weights, bias, in_, out, numReps, stream, options=None):
         out = torch.empty((numReps,) + desc.out_shape, dtype=torch.uint8, device=in_.device)
     _check_tensor(out, (numReps,) + desc.out_shape, "out")
     cd = desc.to_c()
+    if gdn is not None:
+        _lib.check(getattr(L, fn_name + "_gdn")(ctypes.byref(cd), dw.handle, gdn.handle, ctypes.c_void_p(in_.data_ptr()),
+                                                ctypes.c_void_p(out.data_ptr()), numReps, _opt_ptr(options),
+                                                _stream_ptr(stream)), fn_name + "_gdn")
+        return out
     _lib.check(getattr(L, fn_name + "_opt")(ctypes.byref(cd), dw.handle, ctypes.c_void_p(in_.data_ptr()),
                                             ctypes.c_void_p(out.data_ptr()), numReps, _opt_ptr(options),
                                             _stream_ptr(stream)), fn_name)
     return out
 
 
-def conv2d(desc: LayerDesc, weights, bias, in_, out=None, numReps: int = 1, stream=None, options=None):
+def conv2d(desc: LayerDesc, weights, bias, in_, out=None, numReps: int = 1, stream=None, options=None, gdn=None):
     """`conv2d<...>(weights, bias, in, out, numReps)` — conv_nonsquare_top.cpp:198-280.
-    `options`: sicn_options fields as a dict (kernel-selection knobs for tests / experiments)."""
-    return _run("sicn_conv2d", desc, weights, bias, in_, out, numReps, stream, options)
+    `options`: sicn_options fields as a dict (kernel-selection knobs for tests / experiments).
+    `gdn`: a GDN object to apply in place of the ReLU (extension beyond the reference)."""
+    return _run("sicn_conv2d", desc, weights, bias, in_, out, numReps, stream, options, gdn)
 
 
-def deconv522(desc: LayerDesc, weights, bias, in_, out=None, numReps: int = 1, stream=None, options=None):
+def deconv522(desc: LayerDesc, weights, bias, in_, out=None, numReps: int = 1, stream=None, options=None, gdn=None):
     """`deconv522<...>(weights, bias, in, out, numReps)` — conv_nonsquare_top.cpp:71-195."""
-    return _run("sicn_deconv522", desc, weights, bias, in_, out, numReps, stream, options)
+    return _run("sicn_deconv522", desc, weights, bias, in_, out, numReps, stream, options, gdn)
 
 
 # ---- the PARAM:: tables (memdata_nonsquare.h) -------------------------------------------------
@@ -169,7 +214,7 @@ class EightLayersNet:
 
     def __init__(self, width: int = 768, height: int = 512, params=None, device=None,
                  descs: Optional[Sequence[LayerDesc]] = None, shared_weights: Optional[Sequence[DeviceWeights]] = None,
-                 options=None):
+                 options=None, gdn: Optional[Sequence[Optional["GDN"]]] = None):
         import torch
         L = _lib.lib()
         self.descs: List[LayerDesc] = list(descs) if descs is not None else eight_layer_descs(width, height)
@@ -184,7 +229,15 @@ class EightLayersNet:
         cdescs = (CLayerDesc * n)(*[d.to_c() for d in self.descs])
         handles = (ctypes.c_void_p * n)(*[w.handle for w in self.weights])
         self._h = ctypes.c_void_p()
-        _lib.check(L.sicn_net_create_opt(cdescs, handles, n, _opt_ptr(options), ctypes.byref(self._h)), "sicn_net_create_opt")
+        self.gdn = list(gdn) if gdn is not None else None      # keeps the activations alive
+        if self.gdn is not None:
+            if len(self.gdn) != n:
+                raise ValueError("gdn must have one entry (or None) per layer")
+            ghandles = (ctypes.c_void_p * n)(*[(g.handle if g is not None else None) for g in self.gdn])
+            _lib.check(L.sicn_net_create_gdn(cdescs, handles, ghandles, n, _opt_ptr(options), ctypes.byref(self._h)),
+                       "sicn_net_create_gdn")
+        else:
+            _lib.check(L.sicn_net_create_opt(cdescs, handles, n, _opt_ptr(options), ctypes.byref(self._h)), "sicn_net_create_opt")
         self._ws = None
         self._ws_images = 0
 

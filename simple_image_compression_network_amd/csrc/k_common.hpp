@@ -46,11 +46,14 @@ __device__ __forceinline__ void block_barrier()
 // byte's sign is the lane's sign and v_pk_max_i16(x, 0) is the ReLU; a last v_perm_b32 gathers the
 // four high bytes.
 typedef short v2s __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack4_relu7(int a, int b, int c, int d)
+// `floor2`: the two 16-bit lanes the bytes are max'ed against: 0 = the reference's ReLU; ACT_FLOOR_RAW (-32768 in
+// both lanes) makes the max an identity, i.e. the lane BEFORE the ReLU (input of the GDN extension) — same instructions.
+constexpr uint32_t ACT_FLOOR_RELU = 0u, ACT_FLOOR_RAW = 0x80008000u;
+__device__ __forceinline__ uint32_t pack4_relu7(int a, int b, int c, int d, uint32_t floor2 = ACT_FLOOR_RELU)
 {
     const uint32_t ab = __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x040c000cu);  // [0, a.b0, 0, b.b0]
     const uint32_t cd = __builtin_amdgcn_perm((uint32_t)d, (uint32_t)c, 0x040c000cu);
-    const v2s z = {0, 0};
+    const v2s z = __builtin_bit_cast(v2s, floor2);
     const v2s mab = __builtin_elementwise_max(__builtin_bit_cast(v2s, ab), z);
     const v2s mcd = __builtin_elementwise_max(__builtin_bit_cast(v2s, cd), z);
     return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, mcd), __builtin_bit_cast(uint32_t, mab), 0x07050301u);

@@ -1,0 +1,239 @@
+// Fixed-point GDN / IGDN activation (include/sicn_gdn.h; specification: oracle/sicn_gdn_oracle.c).  New
+// functionality — the reference has no GDN (activations.hpp:127-224) — parity status "unpinned".
+//
+//   x_i = max(int8(v_i), -127);  n_i = beta_i + sum_j gamma[i][j] x_j^2;  r_i = floor(2^16 / sqrt(n_i)) or floor(2^8 sqrt(n_i));
+//   y_i = clamp((x_i r_i + 2^(SH-1)) >> SH, -128, 127)
+//
+// k_gdn (C = 128 / 192): the cross-channel sum is a [C x C] x [C x positions] product on v_mfma_i32_16x16x64_i8.
+// x^2 <= 16129 does not fit a byte, so it is split x^2 = 128 hi + lo (hi <= 126, lo <= 127) and the product is run
+// twice over the SAME gamma fragment: acc = gamma*hi; acc = (acc << 7) + beta; acc += gamma*lo.
+// Layout trick (as in k_mfma16.hip): gamma's rows are stored permuted — LDS row 16 j + rho holds channel
+// 64 (j>>2) + 16 (rho>>2) + 4 (j&3) + (rho&3) — so the accumulators a lane ends up with (column = its position, rows
+// 4 g + r) are exactly the 16 consecutive channels 64 J + 16 g .. + 15 that the SAME lane loaded as its 16-byte B-operand
+// chunk: x_i, n_i and the result y_i live in one lane, no cross-lane traffic, and y goes back in place with one
+// 16-byte store per chunk.  A wave owns 64 positions (4 column tiles); the tensor may be in any of the three internal
+// layouts (k_common.hpp), it is only ever addressed as (position, 16-byte channel chunk).
+// k_gdn_generic: any channel count, one thread per output lane, NHWC only (small test shapes).
+#include <vector>
+
+#include "k_common.hpp"
+#include "sicn_gdn_internal.h"
+
+namespace sicn {
+
+// r = max{ r : r^2 n <= 2^32 } = floor(2^16 / sqrt(n)), 1 <= n < 2^30.  Float estimate (within +-1: relative error
+// of cvt + v_rsq_f32 < 2^-21, r <= 46341 for n >= 2) and an exact integer fix-up.
+__device__ __forceinline__ uint32_t gdn_rsqrt16(uint32_t n)
+{
+    if (n <= 1) return 65536u;
+    uint32_t r = (uint32_t)(65536.0f * __frsqrt_rn((float)n));
+    r = min(r, 65535u);
+    auto ok = [&](uint32_t q) {   // q^2 n <= 2^32, q <= 65535 (q^2 fits 32 bits)
+        const uint32_t q2 = q * q, lo = q2 * n, hi = __umulhi(q2, n);
+        return hi == 0 || (hi == 1 && lo == 0);
+    };
+    while (!ok(r)) r--;
+    while (r < 65535u && ok(r + 1)) r++;
+    return r;
+}
+
+// r = max{ r : r^2 <= n 2^16 } = floor(2^8 sqrt(n)), n < 2^30 (r < 2^23).
+__device__ __forceinline__ uint32_t gdn_sqrt8(uint32_t n)
+{
+    const uint32_t nlo = n << 16, nhi = n >> 16;
+    uint32_t r = (uint32_t)(256.0f * __fsqrt_rn((float)n));
+    auto ok = [&](uint32_t q) {
+        const uint32_t lo = q * q, hi = __umulhi(q, q);
+        return hi < nhi || (hi == nhi && lo <= nlo);
+    };
+    while (!ok(r)) r--;
+    while (ok(r + 1)) r++;
+    return r;
+}
+
+__device__ __forceinline__ int gdn_out(int x, uint32_t n, int inverse, int sh)
+{
+    const uint32_t r = inverse ? gdn_sqrt8(n) : gdn_rsqrt16(n);
+    int t = (x * (int)r + (1 << (sh - 1))) >> sh;   // |x r| < 2^30; arithmetic shift
+    return max(-128, min(127, t));
+}
+
+struct GdnMap {   // byte offset of 16-byte chunk k of position p: (p / P) * plane + (p % P) * pix + (k >> 1) * grp + (k & 1) * 16
+    uint32_t P, plane, pix, grp;
+};
+
+template <int NJ>
+__global__ __launch_bounds__(256, 2) void k_gdn(uint8_t *__restrict__ data, const int8_t *__restrict__ gamma_img,
+                                                const uint32_t *__restrict__ beta, long long image_bytes, uint32_t n_pos,
+                                                GdnMap map, int inverse, int sh, int blocks_per_image)
+{
+    constexpr int C = 64 * NJ, NT = C / 16;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *gl = smem;                              // gamma image: [J][j][kg][rho][16 B]
+    uint32_t *bl = (uint32_t *)(smem + C * C);       // beta in natural channel order
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int pos = lane & 15, g = lane >> 4;
+    for (int i = tid; i < C * C / 16; i += 256) ((uint4 *)gl)[i] = ((const uint4 *)gamma_img)[i];
+    for (int i = tid; i < C; i += 256) bl[i] = beta[i];
+    __syncthreads();
+
+    uint8_t *img = data + (size_t)blockIdx.y * (size_t)image_bytes;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, (int)image_bytes, 0x00020000);
+    for (uint32_t blk = blockIdx.x; blk < (uint32_t)blocks_per_image; blk += gridDim.x) {
+#pragma unroll 1
+        for (int c = 0; c < 4; c++) {
+            const uint32_t p = blk * 256u + (uint32_t)(w * 64 + c * 16 + pos);
+            const bool okp = p < n_pos;
+            const uint32_t pl = p / map.P, pr = p - pl * map.P;
+            const uint32_t base = pl * map.plane + pr * map.pix;
+            v4i xf[NJ], hf[NJ], lf[NJ];
+#pragma unroll
+            for (int J = 0; J < NJ; J++) {   // chunk k = 4 J + g: channels 64 J + 16 g .. + 15
+                const uint32_t k = (uint32_t)(4 * J + g);
+                const uint32_t off = okp ? base + (k >> 1) * map.grp + (k & 1u) * 16u : OOB;
+                xf[J] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    uint32_t h = 0, l = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        int v = (int)(int8_t)((uint32_t)xf[J][d] >> (8 * b));
+                        v = max(v, -127);
+                        const uint32_t sq = (uint32_t)(v * v);
+                        h |= (sq >> 7) << (8 * b);
+                        l |= (sq & 127u) << (8 * b);
+                    }
+                    hf[J][d] = (int)h;
+                    lf[J][d] = (int)l;
+                }
+            }
+            v4i acc[NT];
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                v4i gf[NJ];
+#pragma unroll
+                for (int J = 0; J < NJ; J++) gf[J] = *(const v4i *)(gl + (((J * NT + j) * 4 + g) * 16 + pos) * 16);
+                v4i a = {0, 0, 0, 0};
+#pragma unroll
+                for (int J = 0; J < NJ; J++) a = __builtin_amdgcn_mfma_i32_16x16x64_i8(gf[J], hf[J], a, 0, 0, 0);
+                const uint4 b4 = *(const uint4 *)(bl + 64 * (j >> 2) + 16 * g + 4 * (j & 3));
+                a[0] = (a[0] << 7) + (int)b4.x;
+                a[1] = (a[1] << 7) + (int)b4.y;
+                a[2] = (a[2] << 7) + (int)b4.z;
+                a[3] = (a[3] << 7) + (int)b4.w;
+#pragma unroll
+                for (int J = 0; J < NJ; J++) a = __builtin_amdgcn_mfma_i32_16x16x64_i8(gf[J], lf[J], a, 0, 0, 0);
+                acc[j] = a;
+            }
+            // register r of tile j = channel 64 (j>>2) + 16 g + 4 (j&3) + r = byte r of dword (j&3) of this lane's chunk J = j>>2
+#pragma unroll
+            for (int J = 0; J < NJ; J++) {
+                v4i y;
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        int x = (int)(int8_t)((uint32_t)xf[J][d] >> (8 * r));
+                        x = max(x, -127);
+                        const int t = gdn_out(x, (uint32_t)acc[4 * J + d][r], inverse, sh);
+                        packed |= ((uint32_t)t & 255u) << (8 * r);
+                    }
+                    y[d] = (int)packed;
+                }
+                const uint32_t k = (uint32_t)(4 * J + g);
+                const uint32_t off = okp ? base + (k >> 1) * map.grp + (k & 1u) * 16u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(y, rs, off, 0, 0);
+            }
+        }
+    }
+}
+
+// Any channel count (<= 1024), NHWC, in place: a workgroup stages the lanes of `ppb` whole pixels in LDS, then every
+// thread computes output lanes from the staged copy.
+__global__ __launch_bounds__(256) void k_gdn_generic(uint8_t *__restrict__ data, const int8_t *__restrict__ gamma,
+                                                     const uint32_t *__restrict__ beta, long long n_pos, int C, int inverse, int sh,
+                                                     int ppb)
+{
+    __shared__ int8_t px[1024];
+    const long long p0 = (long long)blockIdx.x * ppb;
+    const int n_here = (int)min((long long)ppb, n_pos - p0);
+    for (int e = threadIdx.x; e < n_here * C; e += 256) px[e] = (int8_t)data[p0 * C + e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_here * C; e += 256) {
+        const int q = e / C, i = e - q * C;
+        const int8_t *v = px + q * C;
+        uint32_t n = beta[i];
+        for (int j = 0; j < C; j++) {
+            const int t = max((int)v[j], -127);
+            n += (uint32_t)(uint8_t)gamma[(size_t)i * C + j] * (uint32_t)(t * t);
+        }
+        data[p0 * C + e] = (uint8_t)(gdn_out(max((int)v[i], -127), n, inverse, sh) & 255);
+    }
+}
+
+// gamma [C][C] (row = output channel) -> the LDS image of k_gdn
+void pack_gdn_gamma(const uint8_t *gamma, int C, int8_t *dst)
+{
+    const int NJ = C / 64, NT = C / 16;
+    for (int J = 0; J < NJ; J++)
+        for (int j = 0; j < NT; j++)
+            for (int kg = 0; kg < 4; kg++)
+                for (int rho = 0; rho < 16; rho++) {
+                    const int ch = 64 * (j >> 2) + 16 * (rho >> 2) + 4 * (j & 3) + (rho & 3);
+                    int8_t *o = dst + ((((size_t)J * NT + j) * 4 + kg) * 16 + rho) * 16;
+                    for (int b = 0; b < 16; b++) o[b] = (int8_t)gamma[(size_t)ch * C + 64 * J + 16 * kg + b];
+                }
+}
+
+hipError_t launch_gdn_generic(const sicn_gdn &g, uint8_t *data, long long n_pos, hipStream_t stream);
+
+// layout: LAYOUT_NHWC / GROUP / PHASE of an image of W x H positions; n_images images `image_bytes` apart.
+hipError_t launch_gdn(const sicn_gdn &g, uint8_t *data, int layout, int W, int H, int n_images, hipStream_t stream)
+{
+    const int C = g.channels;
+    const long long hw = (long long)W * H, image_bytes = hw * C;
+    if (image_bytes >= (long long)OOB || n_images > 65535) return hipErrorInvalidValue;
+    if (hw == 0 || n_images == 0) return hipSuccess;
+    if (!g.d_gamma_mfma) {   // channel counts the MFMA kernel does not serve: NHWC only (the generic conv kernel writes NHWC)
+        if (layout != LAYOUT_NHWC) return hipErrorInvalidValue;
+        return launch_gdn_generic(g, data, hw * n_images, stream);
+    }
+    GdnMap m;
+    if (layout == LAYOUT_NHWC) m = GdnMap{(uint32_t)hw, 0u, (uint32_t)C, 32u};
+    else if (layout == LAYOUT_GROUP) m = GdnMap{(uint32_t)hw, 0u, 32u, (uint32_t)hw * 32u};
+    else {
+        if ((W & 1) || (H & 1)) return hipErrorInvalidValue;
+        const uint32_t q = (uint32_t)(hw / 4);
+        m = GdnMap{q, (uint32_t)(C / 32) * q * 32u, 32u, q * 32u};
+    }
+    const int blocks = (int)((hw + 255) / 256);
+    const int gx = blocks < 2048 ? blocks : 2048;   // a workgroup re-uses its gamma image over several blocks
+    const size_t lds = (size_t)C * C + (size_t)C * 4;
+    if (C == 128) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_gdn<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_gdn<2>, dim3((unsigned)gx, (unsigned)n_images), dim3(256), lds, stream, data, g.d_gamma_mfma, g.d_beta,
+                           image_bytes, (uint32_t)hw, m, g.inverse, g.shift, blocks);
+    } else {
+        hipError_t e = hipFuncSetAttribute((const void *)k_gdn<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_gdn<3>, dim3((unsigned)gx, (unsigned)n_images), dim3(256), lds, stream, data, g.d_gamma_mfma, g.d_beta,
+                           image_bytes, (uint32_t)hw, m, g.inverse, g.shift, blocks);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_gdn_generic(const sicn_gdn &g, uint8_t *data, long long n_pos, hipStream_t stream)
+{
+    if (n_pos == 0) return hipSuccess;
+    if (g.channels > 1024) return hipErrorInvalidValue;
+    const int ppb = g.channels <= 1024 ? (1024 / g.channels) : 1;
+    const long long blocks = (n_pos + ppb - 1) / ppb;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_gdn_generic, dim3((unsigned)blocks), dim3(256), 0, stream, data, g.d_gamma, g.d_beta, n_pos, g.channels,
+                       g.inverse, g.shift, ppb);
+    return hipGetLastError();
+}
+
+}  // namespace sicn

@@ -13,7 +13,7 @@ namespace sicn {
 __global__ __launch_bounds__(256) void k_generic(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                  const int8_t *__restrict__ w_okc,
                                                  const int8_t *__restrict__ bias, int IW, int IH, int C,
-                                                 int OW, int OH, int N, int transposed)
+                                                 int OW, int OH, int N, int transposed, int relu)
 {
     const size_t total = (size_t)OH * OW * N;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -43,17 +43,17 @@ __global__ __launch_bounds__(256) void k_generic(const uint8_t *__restrict__ in,
             for (int c = 0; c < C; c++) acc += (int)s[c] * (int)wk[c];
         }
     const int v = acc & 0xFF;
-    out[(size_t)img * total + idx] = (uint8_t)((v & 0x80) ? 0 : v);
+    out[(size_t)img * total + idx] = (uint8_t)((relu && (v & 0x80)) ? 0 : v);
 }
 
 hipError_t launch_generic(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                          int n_images, hipStream_t stream)
+                          int n_images, hipStream_t stream, bool relu)
 {
     const size_t total = (size_t)g.OH * g.OW * g.COUT;
     const size_t blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffu) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_generic, dim3((unsigned)blocks, (unsigned)n_images), dim3(256), 0, stream, in, out,
-                       w.d_w_okc, w.d_bias, g.IW, g.IH, g.CIN, g.OW, g.OH, g.COUT, g.transposed);
+                       w.d_w_okc, w.d_bias, g.IW, g.IH, g.CIN, g.OW, g.OH, g.COUT, g.transposed, relu ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -129,7 +129,7 @@ __device__ __forceinline__ void pass16(v4i (&acc)[Geo<TX>::NC][NT16], const uint
 template <int TX, int NT16>
 __device__ __forceinline__ void store_tiles16(const v4i (&acc)[Geo<TX>::NC][NT16], uint8_t *out_img, int out_img_bytes,
                                               const TensorMap &om, int MW, int MH, int Y0, int X0, int w, int pos, int g,
-                                              bool deconv, int py, int px)
+                                              bool deconv, int py, int px, uint32_t act_floor)
 {
     constexpr int NC = Geo<TX>::NC, XT = Geo<TX>::XT;
     __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)out_img, 0, out_img_bytes, 0x00020000);
@@ -143,10 +143,10 @@ __device__ __forceinline__ void store_tiles16(const v4i (&acc)[Geo<TX>::NC][NT16
 #pragma unroll
         for (int J = 0; J < NT16 / 4; J++) {
             v4i v;
-            v[0] = (int)pack4_relu7(acc[c][4 * J + 0][0], acc[c][4 * J + 0][1], acc[c][4 * J + 0][2], acc[c][4 * J + 0][3]);
-            v[1] = (int)pack4_relu7(acc[c][4 * J + 1][0], acc[c][4 * J + 1][1], acc[c][4 * J + 1][2], acc[c][4 * J + 1][3]);
-            v[2] = (int)pack4_relu7(acc[c][4 * J + 2][0], acc[c][4 * J + 2][1], acc[c][4 * J + 2][2], acc[c][4 * J + 2][3]);
-            v[3] = (int)pack4_relu7(acc[c][4 * J + 3][0], acc[c][4 * J + 3][1], acc[c][4 * J + 3][2], acc[c][4 * J + 3][3]);
+            v[0] = (int)pack4_relu7(acc[c][4 * J + 0][0], acc[c][4 * J + 0][1], acc[c][4 * J + 0][2], acc[c][4 * J + 0][3], act_floor);
+            v[1] = (int)pack4_relu7(acc[c][4 * J + 1][0], acc[c][4 * J + 1][1], acc[c][4 * J + 1][2], acc[c][4 * J + 1][3], act_floor);
+            v[2] = (int)pack4_relu7(acc[c][4 * J + 2][0], acc[c][4 * J + 2][1], acc[c][4 * J + 2][2], acc[c][4 * J + 2][3], act_floor);
+            v[3] = (int)pack4_relu7(acc[c][4 * J + 3][0], acc[c][4 * J + 3][1], acc[c][4 * J + 3][2], acc[c][4 * J + 3][3], act_floor);
             __builtin_amdgcn_raw_buffer_store_b128(v, ro, ok ? off0 + (uint32_t)(2 * J) * om.grp : OOB, 0, 0);
         }
     }
@@ -227,7 +227,7 @@ template <int NQ, int NT16, bool DECONV, int MINW, int TX>
 __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
     const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int8_t *__restrict__ wstream,
     const int8_t *__restrict__ bias, int IW, int IH, int OW, int OH, int MW, int MH, int tiles_x, int n_tiles, int n_images,
-    int in_layout, int out_layout)
+    int in_layout, int out_layout, uint32_t act_floor)
 {
     static_assert(NQ % 2 == 0, "channel groups are consumed in pairs");
     constexpr int CIN = NQ * 32, COUT = NT16 * 16;
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
                 step += NQ;
             }
             if (ph == 3) wait_vmcnt<0>();  // the padded tail of the weight prefetch must land before exit
-            store_tiles16<TX, NT16>(acc, out_img, out_img_bytes, om, MW, MH, Y0, X0, w, pos, g, true, py, px);
+            store_tiles16<TX, NT16>(acc, out_img, out_img_bytes, om, MW, MH, Y0, X0, w, pos, g, true, py, px, act_floor);
         }
     } else {
         // ---- per-lane source offsets of the 4 planes x 3 refresh slots (channel group 0) --------
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
 #pragma unroll 1
         for (int q0 = 0; q0 < NQ; q0 += 2) conv_passes16<TX, NT16, 0>(acc, ctx, poff, q0, qstride);
         wait_vmcnt<0>();
-        store_tiles16<TX, NT16>(acc, out_img, out_img_bytes, om, MW, MH, Y0, X0, w, pos, g, false, 0, 0);
+        store_tiles16<TX, NT16>(acc, out_img, out_img_bytes, om, MW, MH, Y0, X0, w, pos, g, false, 0, 0, act_floor);
     }
 }
 
@@ -350,7 +350,7 @@ constexpr int minw16(int NQ, int NT16, int TX) { return (TX == 16 || (NT16 <= 8 
 #define SICN_INST16(NQ, NT16, D, TX)                                                                             \
     template __global__ void k_mfma16_t<NQ, NT16, D, minw16(NQ, NT16, TX), TX>(                                    \
         const uint8_t *__restrict__, uint8_t *__restrict__, const int8_t *__restrict__, const int8_t *__restrict__, \
-        int, int, int, int, int, int, int, int, int, int, int);
+        int, int, int, int, int, int, int, int, int, int, int, uint32_t);
 SICN_INST16(4, 8, true, 32)
 SICN_INST16(6, 8, true, 32)
 SICN_INST16(4, 8, false, 32)
@@ -359,11 +359,16 @@ SICN_INST16(4, 8, true, 16)
 SICN_INST16(6, 8, true, 16)
 SICN_INST16(4, 8, false, 16)
 SICN_INST16(4, 12, false, 16)
+// shapes of the hyperprior stacks (extension): conv 192 -> 128, deconv 128 -> 192
+SICN_INST16(6, 8, false, 32)
+SICN_INST16(6, 8, false, 16)
+SICN_INST16(4, 12, true, 32)
+SICN_INST16(4, 12, true, 16)
 #undef SICN_INST16
 
 template <int NQ, int NT16, bool DECONV, int TX>
 static hipError_t launch16_tx(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
-                              hipStream_t stream, int in_layout, int out_layout)
+                              hipStream_t stream, int in_layout, int out_layout, bool relu)
 {
     constexpr int NSUB = DECONV ? NQ : 4;
     constexpr int MINW = minw16(NQ, NT16, TX);
@@ -375,7 +380,8 @@ static hipError_t launch16_tx(const LayerGeom &g, const sicn_weights &w, const u
     if (e != hipSuccess) return e;
     dim3 grid(xcd_grid_size(tiles_x * tiles_y * n_images));
     hipLaunchKernelGGL((k_mfma16_t<NQ, NT16, DECONV, MINW, TX>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias,
-                       g.IW, g.IH, g.OW, g.OH, MW, MH, tiles_x, tiles_x * tiles_y, n_images, in_layout, out_layout);
+                       g.IW, g.IH, g.OW, g.OH, MW, MH, tiles_x, tiles_x * tiles_y, n_images, in_layout, out_layout,
+                       relu ? ACT_FLOOR_RELU : ACT_FLOOR_RAW);
     return hipGetLastError();
 }
 
@@ -384,28 +390,30 @@ static hipError_t launch16_tx(const LayerGeom &g, const sicn_weights &w, const u
 // forces one (experiments, tests).
 template <int NQ, int NT16, bool DECONV>
 static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
-                           hipStream_t stream, int in_layout, int out_layout, const sicn_options &o)
+                           hipStream_t stream, int in_layout, int out_layout, const sicn_options &o, bool relu)
 {
     const int MW = DECONV ? g.IW : g.OW, MH = DECONV ? g.IH : g.OH;
     const long tiles32 = (long)((MW + 31) / 32) * ((MH + TILE_Y - 1) / TILE_Y) * n_images;
     bool narrow = minw16(NQ, NT16, 32) == 1 || tiles32 < 2 * 256;
     if (o.tile_x == 16) narrow = true;
     if (o.tile_x == 32) narrow = false;
-    return narrow ? launch16_tx<NQ, NT16, DECONV, 16>(g, w, in, out, n_images, stream, in_layout, out_layout)
-                  : launch16_tx<NQ, NT16, DECONV, 32>(g, w, in, out, n_images, stream, in_layout, out_layout);
+    return narrow ? launch16_tx<NQ, NT16, DECONV, 16>(g, w, in, out, n_images, stream, in_layout, out_layout, relu)
+                  : launch16_tx<NQ, NT16, DECONV, 32>(g, w, in, out, n_images, stream, in_layout, out_layout, relu);
 }
 
 hipError_t launch_mfma16(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
-                         hipStream_t stream, int in_layout, int out_layout, const sicn_options &o)
+                         hipStream_t stream, int in_layout, int out_layout, const sicn_options &o, bool relu)
 {
     if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB) return hipErrorInvalidValue;          // 31-bit patch offsets
     if ((size_t)g.OH * g.OW * g.COUT >= (size_t)OOB) return hipErrorInvalidValue;         // buffer-descriptor stores
     if (g.transposed) {
-        if (g.CIN == 128 && g.COUT == 128) return launch16<4, 8, true>(g, w, in, out, n_images, stream, in_layout, out_layout, o);
-        if (g.CIN == 192 && g.COUT == 128) return launch16<6, 8, true>(g, w, in, out, n_images, stream, in_layout, out_layout, o);
+        if (g.CIN == 128 && g.COUT == 128) return launch16<4, 8, true>(g, w, in, out, n_images, stream, in_layout, out_layout, o, relu);
+        if (g.CIN == 192 && g.COUT == 128) return launch16<6, 8, true>(g, w, in, out, n_images, stream, in_layout, out_layout, o, relu);
+        if (g.CIN == 128 && g.COUT == 192) return launch16<4, 12, true>(g, w, in, out, n_images, stream, in_layout, out_layout, o, relu);
     } else {
-        if (g.CIN == 128 && g.COUT == 128) return launch16<4, 8, false>(g, w, in, out, n_images, stream, in_layout, out_layout, o);
-        if (g.CIN == 128 && g.COUT == 192) return launch16<4, 12, false>(g, w, in, out, n_images, stream, in_layout, out_layout, o);
+        if (g.CIN == 192 && g.COUT == 128) return launch16<6, 8, false>(g, w, in, out, n_images, stream, in_layout, out_layout, o, relu);
+        if (g.CIN == 128 && g.COUT == 128) return launch16<4, 8, false>(g, w, in, out, n_images, stream, in_layout, out_layout, o, relu);
+        if (g.CIN == 128 && g.COUT == 192) return launch16<4, 12, false>(g, w, in, out, n_images, stream, in_layout, out_layout, o, relu);
     }
     return hipErrorInvalidValue;
 }

@@ -72,7 +72,7 @@ template <int NTJ>
 __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                const int8_t *__restrict__ w_l0,
                                                const int8_t *__restrict__ bias, int IW, int IH, int OW,
-                                               int OH, int tiles_y, int ty_per, int out_layout)
+                                               int OH, int tiles_y, int ty_per, int out_layout, uint32_t act_floor)
 {
     constexpr int COUT = NTJ * 32;
     constexpr int TB = COUT * KSTEP;
@@ -180,10 +180,10 @@ __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, u
             for (int j = 0; j < NTJ; j++) {
                 const v16i a = acc[i][j];
                 v4i v;
-                v[0] = (int)pack4_relu7(a[0], a[1], a[2], a[3]);
-                v[1] = (int)pack4_relu7(a[4], a[5], a[6], a[7]);
-                v[2] = (int)pack4_relu7(a[8], a[9], a[10], a[11]);
-                v[3] = (int)pack4_relu7(a[12], a[13], a[14], a[15]);
+                v[0] = (int)pack4_relu7(a[0], a[1], a[2], a[3], act_floor);
+                v[1] = (int)pack4_relu7(a[4], a[5], a[6], a[7], act_floor);
+                v[2] = (int)pack4_relu7(a[8], a[9], a[10], a[11], act_floor);
+                v[3] = (int)pack4_relu7(a[12], a[13], a[14], a[15], act_floor);
                 const uint32_t off = ok ? tensor_offset(om, gy, gx, (uint32_t)j) + 16u * kh : OOB;
                 __builtin_amdgcn_raw_buffer_store_b128(v, ro, off, 0, 0);
             }
@@ -216,7 +216,7 @@ void pack_l0(const int8_t *w_okc, int cout, int8_t *dst)
 }
 
 hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream, int out_layout, const sicn_options &o)
+                     int n_images, hipStream_t stream, int out_layout, const sicn_options &o, bool relu)
 {
     const int tiles_x = (g.OW + TILE_X - 1) / TILE_X, tiles_y = (g.OH + L0_TY - 1) / L0_TY;
     // runs of at most L0_CHUNK tiles (the LDS holds a run's pixels), evened out; the test hook can only shorten them
@@ -235,7 +235,7 @@ hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
         hipError_t e = hipFuncSetAttribute((const void *)k_l0<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_l0<4>, grid, dim3(256), lds, stream, in, out, w.d_w_l0, w.d_bias, g.IW, g.IH,
-                           g.OW, g.OH, tiles_y, ty_per, out_layout);
+                           g.OW, g.OH, tiles_y, ty_per, out_layout, relu ? ACT_FLOOR_RELU : ACT_FLOOR_RAW);
     } else
         return hipErrorInvalidValue;
     return hipGetLastError();

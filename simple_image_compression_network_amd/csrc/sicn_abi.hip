@@ -7,6 +7,7 @@
 #include <new>
 #include <vector>
 
+#include "sicn_gdn_internal.h"
 #include "sicn_internal.h"
 
 using namespace sicn;
@@ -199,10 +200,12 @@ extern "C" int sicn_weights_from_finn_tiles(const sicn_layer_desc *d, const void
     }
     try {
         if (ok && mfma_supported(cin, cout, d->transposed)) {
-            std::vector<int8_t> s(mfma_stream_bytes(cin, cout));
-            pack_mfma_stream(w_okc.data(), cin, cout, d->transposed, s.data());
-            w->mfma_steps = mfma_stream_steps(cin);
-            ok = upload(s.data(), s.size(), &w->d_w_mfma);
+            if (mfma32_supported(cin, cout, d->transposed)) {   // second implementation (sicn_options.mfma_shape = 32)
+                std::vector<int8_t> s(mfma_stream_bytes(cin, cout));
+                pack_mfma_stream(w_okc.data(), cin, cout, d->transposed, s.data());
+                w->mfma_steps = mfma_stream_steps(cin);
+                ok = upload(s.data(), s.size(), &w->d_w_mfma);
+            }
             if (ok) {
                 std::vector<int8_t> s16(mfma16_stream_bytes(cin, cout));
                 pack_mfma16_stream(w_okc.data(), cin, cout, d->transposed, s16.data());
@@ -231,9 +234,17 @@ extern "C" int sicn_weights_from_finn_tiles(const sicn_layer_desc *d, const void
 // ---- single layers ------------------------------------------------------------------------------
 // Layout of the tensor between layer `p` (producer) and layer `c` (consumer) of a chain: the best
 // one both kernels implement (k_common.hpp).  0 = NHWC, 1 = GROUP, 2 = PHASE.
-static int link_layout(const sicn_layer_desc &p, const sicn_layer_desc &c, const sicn_options &o)
+// the kernel family a layer runs on: the RGB deconv kernel has no pre-ReLU output, so a layer-7-shaped layer with a
+// GDN goes to the shape-agnostic kernel
+static KernelKind layer_kernel(const sicn_layer_desc &d, const sicn_options &o, bool has_gdn)
 {
-    const KernelKind kp = pick_kernel(p, o), kc = pick_kernel(c, o);
+    const KernelKind k = pick_kernel(d, o);
+    return (has_gdn && k == KK_L7_RGB) ? KK_GENERIC : k;
+}
+
+static int link_layout(const sicn_layer_desc &p, const sicn_layer_desc &c, const sicn_options &o, bool p_gdn, bool c_gdn)
+{
+    const KernelKind kp = layer_kernel(p, o, p_gdn), kc = layer_kernel(c, o, c_gdn);
     const bool w_group = kp == KK_MFMA_CONV || kp == KK_MFMA_DECONV || kp == KK_L0_RGB;
     const bool w_phase = kp == KK_MFMA_DECONV;   // its outputs come one pixel parity at a time
     const bool r_group = kc == KK_MFMA_CONV || kc == KK_MFMA_DECONV || kc == KK_L7_RGB;
@@ -245,9 +256,11 @@ static int link_layout(const sicn_layer_desc &p, const sicn_layer_desc &c, const
     return 0;
 }
 
+// gdn != nullptr: the layer stores its lanes BEFORE the sign-bit ReLU and the GDN / IGDN kernel then rewrites them in
+// place, in whatever layout the layer wrote (include/sicn_gdn.h; extension beyond the reference).
 static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint8_t *in, uint8_t *out,
                      int n_images, hipStream_t stream, int want_transposed, const sicn_options &o, int in_layout = 0,
-                     int out_layout = 0)
+                     int out_layout = 0, const sicn_gdn *gdn = nullptr)
 {
     int rc = sicn_validate_desc(d);
     if (rc) return rc;
@@ -256,20 +269,24 @@ static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint
     if (w->cin != d->IFM_CH || w->cout != d->OFM_CH || w->transposed != d->transposed) return SICN_EINVAL;
     if (n_images == 0) return SICN_OK;
     if (n_images > 65535) return SICN_EINVAL;
+    if (gdn && gdn->channels != d->OFM_CH) return SICN_EINVAL;
     const LayerGeom g = geom_of(*d);
+    const bool relu = gdn == nullptr;
     hipError_t e;
-    switch (pick_kernel(*d, o)) {
-    case KK_L0_RGB: e = launch_l0(g, *w, in, out, n_images, stream, out_layout, o); break;
+    switch (layer_kernel(*d, o, gdn != nullptr)) {
+    case KK_L0_RGB: e = launch_l0(g, *w, in, out, n_images, stream, out_layout, o, relu); break;
     case KK_L7_RGB: e = launch_l7(g, *w, in, out, n_images, stream, in_layout, o); break;
     case KK_MFMA_CONV:
     case KK_MFMA_DECONV:
         // MFMA shape: 16x16x64 by default (higher sustained clock, k_mfma16.hip); mfma_shape = 32 selects
-        // the 32x32x32 kernels of k_mfma.hip (a second implementation kept under test)
-        e = o.mfma_shape == 32 ? launch_mfma(g, *w, in, out, n_images, stream, in_layout, out_layout)
-                               : launch_mfma16(g, *w, in, out, n_images, stream, in_layout, out_layout, o);
+        // the 32x32x32 kernels of k_mfma.hip (a second implementation kept under test; reference shapes, ReLU only)
+        e = (o.mfma_shape == 32 && relu && mfma32_supported(d->IFM_CH, d->OFM_CH, d->transposed))
+                ? launch_mfma(g, *w, in, out, n_images, stream, in_layout, out_layout)
+                : launch_mfma16(g, *w, in, out, n_images, stream, in_layout, out_layout, o, relu);
         break;
-    default: e = launch_generic(g, *w, in, out, n_images, stream); break;
+    default: e = launch_generic(g, *w, in, out, n_images, stream, relu); break;
     }
+    if (e == hipSuccess && gdn) e = launch_gdn(*gdn, out, out_layout, d->OFM_ROW, d->OFM_COL, n_images, stream);
     if (e == hipErrorInvalidValue) return SICN_EINVAL;
     return e == hipSuccess ? SICN_OK : SICN_ENODEV;
 }
@@ -306,6 +323,7 @@ extern "C" int sicn_deconv522_opt(const sicn_layer_desc *d, const sicn_weights *
 struct sicn_net {
     std::vector<sicn_layer_desc> descs;
     std::vector<const sicn_weights *> weights;
+    std::vector<const sicn_gdn *> gdn;         // per layer, nullptr = the reference's ReLU
     sicn_options opt;                          // fixed at creation
     // profiling: the only state a launch changes.  One flat ring of event pairs; a forward call reserves the
     // slots of its layers with one atomic fetch_add, so calls on several streams / threads never share a slot.
@@ -329,6 +347,12 @@ extern "C" int sicn_net_create(const sicn_layer_desc *descs, sicn_weights *const
 extern "C" int sicn_net_create_opt(const sicn_layer_desc *descs, sicn_weights *const *weights, int n_layers,
                                    const sicn_options *opt, sicn_net **out)
 {
+    return sicn_net_create_gdn(descs, weights, nullptr, n_layers, opt, out);
+}
+
+extern "C" int sicn_net_create_gdn(const sicn_layer_desc *descs, sicn_weights *const *weights, const sicn_gdn *const *gdn,
+                                   int n_layers, const sicn_options *opt, sicn_net **out)
+{
     if (!out) return SICN_EINVAL;
     *out = nullptr;
     if (!descs || !weights || n_layers <= 0 || n_layers > 64) return SICN_EINVAL;
@@ -343,12 +367,15 @@ extern "C" int sicn_net_create_opt(const sicn_layer_desc *descs, sicn_weights *c
         if (i > 0 && (descs[i].IFM_CH != descs[i - 1].OFM_CH || descs[i].IFM_ROW != descs[i - 1].OFM_ROW ||
                       descs[i].IFM_COL != descs[i - 1].OFM_COL))
             return SICN_EINVAL;
+        if (gdn && gdn[i] && gdn[i]->channels != descs[i].OFM_CH) return SICN_EINVAL;
     }
     sicn_net *net = new (std::nothrow) sicn_net();
     if (!net) return SICN_ENOMEM;
     try {
         net->descs.assign(descs, descs + n_layers);
         net->weights.assign(weights, weights + n_layers);
+        net->gdn.assign((size_t)n_layers, nullptr);
+        if (gdn) net->gdn.assign(gdn, gdn + n_layers);
         net->opt = o;
     } catch (const std::bad_alloc &) {
         delete net;
@@ -405,13 +432,16 @@ extern "C" int sicn_net_forward(const sicn_net *net, int first, int last, const 
     for (int l = first; l <= last; l++) {
         uint8_t *dst = (l == last) ? out : pp[(l - first) & 1];
         // intermediates nobody outside sees travel in the grouped layout when both neighbours can
-        const int out_layout = (l < last && l != tap_layer) ? link_layout(net->descs[l], net->descs[l + 1], net->opt) : 0;
+        const int out_layout = (l < last && l != tap_layer)
+                                   ? link_layout(net->descs[l], net->descs[l + 1], net->opt, net->gdn[l] != nullptr, net->gdn[l + 1] != nullptr)
+                                   : 0;
         const int slot = slot0 >= 0 ? slot0 + (l - first) : -1;
         if (slot >= 0) {
             net->ev_layer[slot] = -1;   // becomes l once both events are recorded
             if (hipEventRecord(net->ev_begin[slot], stream) != hipSuccess) return SICN_ENODEV;
         }
-        int rc = run_layer(&net->descs[l], net->weights[l], cur, dst, n_images, stream, -1, net->opt, cur_layout, out_layout);
+        int rc = run_layer(&net->descs[l], net->weights[l], cur, dst, n_images, stream, -1, net->opt, cur_layout, out_layout,
+                           net->gdn[l]);
         if (rc) return rc;
         if (slot >= 0) {
             if (hipEventRecord(net->ev_end[slot], stream) != hipSuccess) return SICN_ENODEV;
@@ -493,4 +523,76 @@ extern "C" int sicn_net_layer_ms(sicn_net *net, int reset, float *ms_sum, int *l
         net->ev_next.store(0, std::memory_order_release);
     }
     return SICN_OK;
+}
+
+// ---- GDN / IGDN activation objects (include/sicn_gdn.h; extension beyond the reference) ------------------------
+extern "C" void sicn_gdn_free(sicn_gdn *g)
+{
+    if (!g) return;
+    if (g->d_beta) (void)hipFree(g->d_beta);
+    if (g->d_gamma) (void)hipFree(g->d_gamma);
+    if (g->d_gamma_mfma) (void)hipFree(g->d_gamma_mfma);
+    delete g;
+}
+
+extern "C" int sicn_gdn_create(int channels, int inverse, int shift, const uint32_t *beta, const uint8_t *gamma, sicn_gdn **out)
+{
+    if (!out) return SICN_EINVAL;
+    *out = nullptr;
+    if (channels <= 0 || channels > 1024 || (inverse != 0 && inverse != 1) || shift < 1 || shift > 24 || !beta || !gamma)
+        return SICN_EINVAL;
+    for (int i = 0; i < channels; i++) {
+        if (beta[i] < 1 || beta[i] > 65535) return SICN_EINVAL;
+        for (int j = 0; j < channels; j++)
+            if (gamma[(size_t)i * channels + j] > 127) return SICN_EINVAL;
+    }
+    sicn_gdn *g = new (std::nothrow) sicn_gdn();
+    if (!g) return SICN_ENOMEM;
+    *g = sicn_gdn{channels, inverse, shift, nullptr, nullptr, nullptr};
+    bool ok = upload(beta, (size_t)channels * 4, (int8_t **)&g->d_beta) &&
+              upload(gamma, (size_t)channels * channels, &g->d_gamma);
+    if (ok && (channels == 128 || channels == 192)) {
+        try {
+            std::vector<int8_t> img((size_t)channels * channels);
+            pack_gdn_gamma(gamma, channels, img.data());
+            ok = upload(img.data(), img.size(), &g->d_gamma_mfma);
+        } catch (const std::bad_alloc &) { ok = false; }
+    }
+    if (!ok) {
+        sicn_gdn_free(g);
+        return SICN_ENOMEM;
+    }
+    *out = g;
+    return SICN_OK;
+}
+
+extern "C" int sicn_gdn_apply(const sicn_gdn *g, uint8_t *lanes, long long n_positions, void *hip_stream)
+{
+    if (!g || n_positions < 0 || (n_positions && !lanes)) return SICN_EINVAL;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    // chunks of at most 2^23 positions (x 192 B < 2 GiB: the kernel addresses a chunk through one buffer descriptor)
+    const long long chunk = 1LL << 23;
+    for (long long p = 0; p < n_positions; p += chunk) {
+        const long long n = n_positions - p < chunk ? n_positions - p : chunk;
+        hipError_t e = launch_gdn(*g, lanes + (size_t)p * g->channels, 0 /* NHWC */, (int)n, 1, 1, stream);
+        if (e == hipErrorInvalidValue) return SICN_EINVAL;
+        if (e != hipSuccess) return SICN_ENODEV;
+    }
+    return SICN_OK;
+}
+
+extern "C" int sicn_conv2d_gdn(const sicn_layer_desc *d, const sicn_weights *w, const sicn_gdn *gdn, const uint8_t *in,
+                               uint8_t *out, int n_images, const sicn_options *opt, void *hip_stream)
+{
+    sicn_options o;
+    int rc = resolve_options(opt, &o);
+    return rc ? rc : run_layer(d, w, in, out, n_images, (hipStream_t)hip_stream, 0, o, 0, 0, gdn);
+}
+
+extern "C" int sicn_deconv522_gdn(const sicn_layer_desc *d, const sicn_weights *w, const sicn_gdn *gdn, const uint8_t *in,
+                                  uint8_t *out, int n_images, const sicn_options *opt, void *hip_stream)
+{
+    sicn_options o;
+    int rc = resolve_options(opt, &o);
+    return rc ? rc : run_layer(d, w, in, out, n_images, (hipStream_t)hip_stream, 1, o, 0, 0, gdn);
 }

@@ -1,0 +1,18 @@
+// Internal: the GDN / IGDN activation object (include/sicn_gdn.h) and its launchers (k_gdn.hip).
+#pragma once
+#include "../../include/sicn_gdn.h"
+#include "sicn_internal.h"
+
+struct sicn_gdn {
+    int channels, inverse, shift;
+    uint32_t *d_beta;      // [C] natural channel order
+    int8_t *d_gamma;       // [C][C] natural order (generic kernel)
+    int8_t *d_gamma_mfma;  // permuted LDS image of k_gdn, or nullptr when C is not 128 / 192
+};
+
+namespace sicn {
+void pack_gdn_gamma(const uint8_t *gamma, int C, int8_t *dst);
+// in place over n_images images of W x H positions in the given internal layout (k_common.hpp LAYOUT_*)
+hipError_t launch_gdn(const sicn_gdn &g, uint8_t *data, int layout, int W, int H, int n_images, hipStream_t stream);
+hipError_t launch_gdn_generic(const sicn_gdn &g, uint8_t *data, long long n_pos, hipStream_t stream);
+}  // namespace sicn

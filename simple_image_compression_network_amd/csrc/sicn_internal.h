@@ -58,15 +58,16 @@ struct DebugEnv { int mfma_variant, debug_kernel, extra_lds; };
 const DebugEnv &debug_env();
 
 // Launchers: enqueue on `stream`, return hipError_t of the launch.
+// relu = false: store the lane BEFORE the sign-bit ReLU (input of the GDN extension, include/sicn_gdn.h)
 hipError_t launch_generic(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                          int n_images, hipStream_t stream);
+                          int n_images, hipStream_t stream, bool relu = true);
 // in_layout / out_layout: LAYOUT_NHWC (the ABI layout) / LAYOUT_GROUP / LAYOUT_PHASE (k_common.hpp)
 hipError_t launch_mfma(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
                        int n_images, hipStream_t stream, int in_layout, int out_layout);
 hipError_t launch_mfma16(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                         int n_images, hipStream_t stream, int in_layout, int out_layout, const sicn_options &o);
+                         int n_images, hipStream_t stream, int in_layout, int out_layout, const sicn_options &o, bool relu = true);
 hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream, int out_layout, const sicn_options &o);
+                     int n_images, hipStream_t stream, int out_layout, const sicn_options &o, bool relu = true);
 hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
                      int n_images, hipStream_t stream, int in_layout, const sicn_options &o);
 
@@ -76,6 +77,7 @@ size_t mfma_stream_bytes(int cin, int cout);
 int mfma_stream_steps(int cin);
 void pack_mfma_stream(const int8_t *w_okc, int cin, int cout, int transposed, int8_t *dst);
 bool mfma_supported(int cin, int cout, int transposed);
+bool mfma32_supported(int cin, int cout, int transposed);
 size_t mfma16_stream_bytes(int cin, int cout);
 void pack_mfma16_stream(const int8_t *w_okc, int cin, int cout, int transposed, int8_t *dst);
 

@@ -1,0 +1,225 @@
+"""Fixed-point GDN / IGDN (include/sicn_gdn.h).  NEW functionality without a reference counterpart
+(activations.hpp:127-224 has no GDN), parity "unpinned": the CPU tests hold the two independent statements of the
+specification together (oracle/sicn_gdn_oracle.c: integer bisection; oracle/sicn_ref.py: math.isqrt) and check its
+defining properties; the GPU tests show the HIP kernels (MFMA cross-channel sum, float estimate + integer fix-up of the
+square roots) reproduce it bit for bit — standalone, behind every layer kernel family, in every internal layout of a chain."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle, sicn_ref
+from simple_image_compression_network_amd.config import LayerDesc
+
+ROOT = Path(__file__).resolve().parent.parent
+gpu = pytest.mark.gpu
+
+
+def _params(rng, c, kind="random"):
+    if kind == "unit":        # beta = 1.0 (Q8), gamma = 0: y = x * 2^(16-8/2... ) pure scaling
+        return np.full(c, 256, np.uint32), np.zeros((c, c), np.uint8)
+    if kind == "extreme":     # largest n the specification allows
+        return np.full(c, 65535, np.uint32), np.full((c, c), 127, np.uint8)
+    beta = rng.integers(1, 65536, c).astype(np.uint32)
+    gamma = rng.integers(0, 128, (c, c)).astype(np.uint8)
+    gamma[rng.random((c, c)) < 0.5] = 0
+    return beta, gamma
+
+
+@pytest.mark.parametrize("c", [1, 3, 6, 64, 128, 192])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_two_oracle_statements_agree(c, inverse):
+    rng = np.random.default_rng(c * 2 + inverse)
+    x = rng.integers(0, 256, (40, c), dtype=np.uint8)
+    x[0, :] = 0x80                       # -128 is clamped to -127 before squaring
+    x[1, :] = 0x7F
+    x[2, :] = 0
+    for kind in ("random", "unit", "extreme"):
+        beta, gamma = _params(rng, c, kind)
+        for shift in (1, 8, 12, 24):
+            a = c_oracle.gdn(x, beta, gamma, inverse, shift)
+            assert np.array_equal(a, sicn_ref.gdn_ref(x, beta, gamma, inverse, shift)), (kind, shift)
+
+
+def test_specification_properties():
+    rng = np.random.default_rng(5)
+    c = 16
+    x = rng.integers(0, 256, (200, c), dtype=np.uint8)
+    beta, gamma = _params(rng, c, "unit")
+    # beta = 256 (1.0 in Q8), gamma = 0, shift = 12: GDN r = floor(65536/16) = 4096 -> y = x exactly (identity)
+    y = c_oracle.gdn(x, beta, gamma, False, 12).view(np.int8)
+    assert np.array_equal(y, np.maximum(x.view(np.int8), -127))
+    # IGDN with the same parameters: r = floor(256*16) = 4096 -> identity as well
+    y = c_oracle.gdn(x, beta, gamma, True, 12).view(np.int8)
+    assert np.array_equal(y, np.maximum(x.view(np.int8), -127))
+    # odd symmetry: y(-x) = -y(x) up to the rounding offset (floor of (v + half) vs floor of (-v + half))
+    beta, gamma = _params(rng, c)
+    xs = np.maximum(x.view(np.int8), -127)
+    yp = c_oracle.gdn(xs.view(np.uint8), beta, gamma, False, 10).view(np.int8).astype(int)
+    yn = c_oracle.gdn((-xs).astype(np.int8).view(np.uint8), beta, gamma, False, 10).view(np.int8).astype(int)
+    assert np.all(np.abs(yp + yn) <= 1)
+    # GDN divides: more energy in the other channels never increases |y|
+    g2 = gamma.copy()
+    g2[g2 < 127] += 1
+    y1 = np.abs(c_oracle.gdn(x, beta, gamma, False, 10).view(np.int8).astype(int))
+    y2 = np.abs(c_oracle.gdn(x, beta, g2, False, 10).view(np.int8).astype(int))
+    assert np.all(y2 <= y1)
+    # rejected parameters
+    with pytest.raises(RuntimeError):
+        c_oracle.gdn(x, np.zeros(c, np.uint32), gamma, False, 12)          # beta = 0
+    with pytest.raises(RuntimeError):
+        c_oracle.gdn(x, beta, np.full((c, c), 128, np.uint8), False, 12)   # gamma > 127
+
+
+def test_preact_lane_is_the_reference_layer_without_its_relu():
+    """relu7(pre-activation) == the reference layer: the GDN input is exactly conv_nonsquare_top.cpp:272's lane."""
+    rng = np.random.default_rng(9)
+    d = LayerDesc(IFM_CH=6, IFM_ROW=11, IFM_COL=7, OFM_CH=4, OFM_ROW=6, OFM_COL=4, SIMD=3, PE=2, W_TILES=2 * 50)
+    W = rng.integers(-8, 8, (4, 5, 5, 6)).astype(np.int8)
+    b = rng.integers(-128, 128, 4).astype(np.int8)
+    x = rng.integers(0, 256, (7, 11, 6), dtype=np.uint8)
+    words = sicn_ref.pack_finn_tiles(W, 3, 2)
+    pre = c_oracle.run_layer_preact(d, words, b, x)
+    assert np.array_equal(pre, sicn_ref.layer_preact_ref(x, W, b, 0))
+    relu = pre.copy()
+    relu[relu >= 128] = 0
+    assert np.array_equal(relu, c_oracle.run_layer(d, words, b, x, "direct"))
+    assert np.array_equal(relu, sicn_ref.conv2d_ref(x, W, b))
+
+
+def test_gdn_abi_symbols_exported():
+    text = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "sicn_gdn.h").read_text(), flags=re.S)
+    syms = sorted(set(re.findall(r"\b(sicn_[a-z0-9_]+)\s*\(", text)))
+    from simple_image_compression_network_amd import _lib
+    L = _lib.lib()
+    assert set(syms) == set(_lib.GDN_ABI) and all(hasattr(L, s) for s in syms)
+    out = ctypes.c_void_p()
+    beta = (ctypes.c_uint32 * 4)(1, 2, 3, 0)          # beta = 0 is rejected on the host, before any GPU call
+    gamma = (ctypes.c_uint8 * 16)()
+    assert L.sicn_gdn_create(4, 0, 12, beta, gamma, ctypes.byref(out)) == -22
+    assert L.sicn_gdn_create(4, 2, 12, beta, gamma, ctypes.byref(out)) == -22
+    assert L.sicn_gdn_create(4, 0, 0, beta, gamma, ctypes.byref(out)) == -22
+    assert L.sicn_gdn_apply(None, None, 4, None) == -22
+
+
+# ------------------------------------------------------------------------------------------ GPU
+def _mk_desc(cin, cout, simd, pe, w, h, tr):
+    ow, oh = (2 * w, 2 * h) if tr else ((w + 1) // 2, (h + 1) // 2)
+    d = LayerDesc(IFM_CH=cin, IFM_ROW=w, IFM_COL=h, OFM_CH=cout, OFM_ROW=ow, OFM_COL=oh, SIMD=simd, PE=pe,
+                  W_TILES=(cout // pe) * (25 * cin // simd), transposed=tr)
+    d.validate()
+    return d
+
+
+@gpu
+@pytest.mark.parametrize("c", [128, 192, 6, 64, 3])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gpu_gdn_apply_equals_oracle(c, inverse):
+    import torch
+    from simple_image_compression_network_amd import api
+    rng = np.random.default_rng(c + inverse)
+    npos = 1000 if c >= 64 else 333                    # not a multiple of the 256-position block
+    x = rng.integers(0, 256, (npos, c), dtype=np.uint8)
+    x[0, :] = 0x80
+    for kind, shift in (("random", 12), ("extreme", 16), ("unit", 12), ("random", 1), ("random", 24)):
+        beta, gamma = _params(rng, c, kind)
+        g = api.GDN(beta, gamma, inverse, shift)
+        got = g.apply_(torch.from_numpy(x).cuda()).cpu().numpy()
+        ref = c_oracle.gdn(x, beta, gamma, inverse, shift)
+        assert np.array_equal(got, ref), (kind, shift, np.count_nonzero(got != ref))
+
+
+@gpu
+def test_gpu_gdn_square_roots_exhaustive_ranges():
+    """The kernels estimate the square roots in float and fix them up in integers: sweep n densely through the ranges
+    where float rounding could bite (small n, perfect squares +-1, the top of the range) with a 1-channel activation
+    whose n is exactly beta + gamma * x^2."""
+    import torch
+    from simple_image_compression_network_amd import api
+    rng = np.random.default_rng(1)
+    xs = np.arange(256, dtype=np.uint8).reshape(256, 1)
+    betas = np.unique(np.concatenate([np.arange(1, 600), np.arange(16000, 16700), np.arange(65000, 65536),
+                                      (np.arange(2, 256) ** 2), (np.arange(2, 256) ** 2) - 1, (np.arange(2, 256) ** 2) + 1,
+                                      rng.integers(1, 65536, 300)]))
+    for inverse in (False, True):
+        for gam in (0, 1, 127):
+            for beta in betas[:: 7 if gam else 1]:
+                b = np.array([beta], np.uint32)
+                gm = np.array([[gam]], np.uint8)
+                g = api.GDN(b, gm, inverse, 9)
+                got = g.apply_(torch.from_numpy(xs).cuda()).cpu().numpy()
+                assert np.array_equal(got, c_oracle.gdn(xs, b, gm, inverse, 9)), (inverse, gam, int(beta))
+
+
+# every kernel family that can carry a GDN: l0_rgb, mfma_conv (128 and 192 out), mfma_deconv, generic (incl. the RGB-out
+# layer, which the library routes to the generic kernel when it has a GDN)
+GDN_LAYERS = [(3, 128, 3, 8, 70, 38, 0), (128, 128, 8, 16, 66, 18, 0), (128, 192, 8, 24, 40, 22, 0), (192, 128, 12, 16, 33, 9, 1),
+              (128, 128, 8, 16, 34, 10, 1), (128, 3, 8, 3, 20, 7, 1), (6, 6, 2, 3, 13, 9, 0), (192, 128, 12, 16, 37, 21, 0),
+              (128, 192, 8, 24, 19, 11, 1)]
+
+
+@gpu
+@pytest.mark.parametrize("case", GDN_LAYERS)
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gpu_layer_with_gdn_equals_oracle(case, inverse):
+    import torch
+    from simple_image_compression_network_amd import api
+    rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + inverse)
+    d = _mk_desc(*case)
+    W = rng.integers(-8, 8, (d.OFM_CH, 5, 5, d.IFM_CH)).astype(np.int8)
+    b = rng.integers(-128, 128, d.OFM_CH).astype(np.int8)
+    words = sicn_ref.pack_finn_tiles(W, d.SIMD, d.PE)
+    x = rng.integers(0, 256, (2,) + d.in_shape, dtype=np.uint8)
+    beta, gamma = _params(rng, d.OFM_CH)
+    g = api.GDN(beta, gamma, inverse, 12)
+    fpw = api.FixedPointWeights(d.SIMD, 4, d.PE, d.W_TILES, words)
+    fn = api.deconv522 if d.transposed else api.conv2d
+    got = fn(d, fpw, b, torch.from_numpy(x).cuda(), None, 2, gdn=g).cpu().numpy()
+    for i in range(2):
+        pre = sicn_ref.layer_preact_ref(x[i], W, b, d.transposed)
+        assert np.array_equal(got[i], c_oracle.gdn(pre, beta, gamma, inverse, 12)), i
+
+
+@gpu
+@pytest.mark.parametrize("options", [{}, {"tile_x": 16}, {"no_phase_layout": 1}, {"force_generic": 1}])
+def test_gpu_gdn_net_all_internal_layouts(options):
+    """The hyperprior-style main transform: GDN after L0-L2, IGDN after L4-L6 (L3 and L7 keep the reference's ReLU), as one
+    sicn_net chain.  The activations run in place on GROUP / PHASE / NHWC intermediates; latent and reconstruction must
+    equal the oracle's layer-by-layer statement."""
+    import torch
+    from simple_image_compression_network_amd import api
+    from simple_image_compression_network_amd.config import eight_layer_descs
+    rng = np.random.default_rng(42)
+    w, h = (96, 64) if not options.get("force_generic") else (32, 16)
+    descs = eight_layer_descs(w, h)
+    params_np, params, gdns, gdn_np = [], [], [], []
+    for l, d in enumerate(descs):
+        Wt = rng.integers(-8, 8, (d.OFM_CH, 5, 5, d.IFM_CH)).astype(np.int8)
+        bt = rng.integers(-128, 128, d.OFM_CH).astype(np.int8)
+        params_np.append((Wt, bt, d.transposed))
+        params.append((api.FixedPointWeights(d.SIMD, 4, d.PE, d.W_TILES, sicn_ref.pack_finn_tiles(Wt, d.SIMD, d.PE)),
+                       api.FixedPointWeights(1, 8, 1, d.OFM_CH, bt.view(np.uint8).astype(np.uint64))))
+        if l in (0, 1, 2, 4, 5, 6):
+            beta, gamma = _params(rng, d.OFM_CH)
+            gdn_np.append((beta, gamma, l >= 4))
+            gdns.append(api.GDN(beta, gamma, l >= 4, 12))
+        else:
+            gdn_np.append(None)
+            gdns.append(None)
+    net = api.EightLayersNet(w, h, params=params, gdn=gdns, options=options or None)
+    x = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+    out, lat = net.forward(torch.from_numpy(x).cuda())
+    out, lat = out.cpu().numpy(), lat.cpu().numpy()
+    for i in range(2):
+        a = x[i]
+        for l, (Wt, bt, tr) in enumerate(params_np):
+            if gdn_np[l] is None:
+                a = sicn_ref.deconv522_ref(a, Wt, bt) if tr else sicn_ref.conv2d_ref(a, Wt, bt)
+            else:
+                beta, gamma, inv = gdn_np[l]
+                a = c_oracle.gdn(sicn_ref.layer_preact_ref(a, Wt, bt, tr), beta, gamma, inv, 12)
+            if l == 3:
+                assert np.array_equal(lat[i], a), "latent"
+        assert np.array_equal(out[i], a), "reconstruction"
