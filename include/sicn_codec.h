@@ -40,6 +40,7 @@ extern "C" {
 #define SICN_CODEC_PACKED7 1
 #define SICN_CODEC_RANS 2
 #define SICN_CODEC_RANSW 3
+#define SICN_CODEC_RANSWC 4 /* rANS-W with the conditional (hyperprior + checkerboard context) model, see below */
 #define SICN_CODEC_HEADER_BYTES 48
 #define SICN_CODEC_STREAM_SYMBOLS 1024
 #define SICN_CODEC_WSTREAM_SYMBOLS 16384 /* mode 3: 64 lanes x 256 steps */
@@ -100,6 +101,25 @@ int sicn_codec_decode_batch_async(const uint8_t *containers, size_t slot_bytes, 
                                   uint32_t n_images, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c, uint8_t *latents,
                                   size_t latent_stride, sicn_codec_status *status_dev, void *workspace, size_t workspace_bytes,
                                   void *hip_stream);
+
+/* Mode 4, "rANS-WC": the hyperprior / context-model coder (BASELINE.json configs[4]; no reference
+ * counterpart; specification: oracle/sicn_hyper_oracle.c).  Besides the latent both sides hold a SCALE MAP of the same
+ * shape (values < 128; the hyper-synthesis output).  Every symbol is coded with one of 16 static tables carried in the
+ * container; its class is `scale >> 3` for the anchor half of a checkerboard ((x + y) even) and
+ * `min(15, ((scale >> 3) + (max of the 4 anchor neighbours >> 3) + 1) >> 1)` for the other half, which is therefore decoded
+ * in a second pass.  Both passes are rANS-W streams (64 interleaved states per wave).  Asynchronous only: same status
+ * conventions as the pair above; lat_c must be a multiple of 4, latents / scales 4-byte aligned, n images back to back
+ * ([n][lat_h][lat_w][lat_c]). */
+size_t sicn_codec_ctx_max_bytes(uint32_t lat_w, uint32_t lat_h, uint32_t lat_c);
+size_t sicn_codec_ctx_workspace_bytes(uint32_t lat_w, uint32_t lat_h, uint32_t lat_c, uint32_t n_images);
+int sicn_codec_ctx_encode_batch_async(const uint8_t *latents, const uint8_t *scales, uint32_t n_images, uint32_t lat_w,
+                                      uint32_t lat_h, uint32_t lat_c, uint32_t image_width, uint32_t image_height, uint8_t *out,
+                                      size_t slot_bytes, sicn_codec_status *status_dev, void *workspace, size_t workspace_bytes,
+                                      void *hip_stream);
+int sicn_codec_ctx_decode_batch_async(const uint8_t *containers, size_t slot_bytes, const sicn_codec_status *valid_dev_or_null,
+                                      const uint8_t *scales, uint32_t n_images, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c,
+                                      uint8_t *latents, sicn_codec_status *status_dev, void *workspace, size_t workspace_bytes,
+                                      void *hip_stream);
 
 /* Self-test (host arithmetic only, no GPU): checks the rANS-W encoder's reciprocal divide against x / f for
  * f in [f_begin, f_end) over the states the encoder can hold. Returns the number of wrong results (0 = pass). */

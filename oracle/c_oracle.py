@@ -21,7 +21,7 @@ class OrDesc(ctypes.Structure):
 
 def build(force: bool = False) -> Path:
     so = _HERE / "libsicn_oracle.so"
-    srcs = [_HERE / n for n in ("sicn_oracle.c", "sicn_codec_oracle.c", "sicn_gdn_oracle.c")]
+    srcs = [_HERE / n for n in ("sicn_oracle.c", "sicn_codec_oracle.c", "sicn_gdn_oracle.c", "sicn_hyper_oracle.c")]
     if force or not so.exists() or so.stat().st_mtime < max(f.stat().st_mtime for f in srcs):
         subprocess.run(["make", "-C", str(_HERE), "-B", "libsicn_oracle.so"], check=True,
                        capture_output=True)
@@ -45,6 +45,12 @@ def lib() -> ctypes.CDLL:
         L.sicn_or_layer_direct_act.restype = ctypes.c_int
         L.sicn_or_gdn.argtypes = [p, p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, p, p]
         L.sicn_or_gdn.restype = ctypes.c_int
+        L.sicl_or_ctx_max_bytes.argtypes = [ctypes.c_uint32] * 3
+        L.sicl_or_ctx_max_bytes.restype = ctypes.c_size_t
+        L.sicl_or_ctx_encode.argtypes = [p, p] + [ctypes.c_uint32] * 5 + [p, ctypes.c_size_t]
+        L.sicl_or_ctx_encode.restype = ctypes.c_longlong
+        L.sicl_or_ctx_decode.argtypes = [p, ctypes.c_size_t, p, p, ctypes.c_size_t, p]
+        L.sicl_or_ctx_decode.restype = ctypes.c_longlong
         L.sicn_or_swg_nonsquare_fsm.argtypes = [p, ctypes.c_longlong, p] + [ctypes.c_int] * 10
         L.sicn_or_swg_nonsquare_fsm.restype = ctypes.c_longlong
         L.sicn_or_im2col_s1.argtypes = [p, p] + [ctypes.c_int] * 5
@@ -88,6 +94,32 @@ def codec_decode(container: bytes):
     n = L.sicl_or_decode(_ptr(buf), buf.size, _ptr(lat), lat.size, _ptr(info))
     if n < 0:
         raise RuntimeError(f"sicl_or_decode rc={n}")
+    return lat[: int(info[6])].reshape(int(info[4]), int(info[3]), int(info[5])), info
+
+
+def ctx_encode(latent: np.ndarray, scale: np.ndarray, image_wh=(0, 0)) -> bytes:
+    """Container mode 4 (rANS-WC: 16 class tables, checkerboard context; oracle/sicn_hyper_oracle.c). [h][w][c] uint8 each."""
+    latent = np.ascontiguousarray(latent, dtype=np.uint8)
+    scale = np.ascontiguousarray(scale, dtype=np.uint8)
+    assert latent.shape == scale.shape and latent.ndim == 3
+    h, w, c = latent.shape
+    L = lib()
+    out = np.zeros(max(L.sicl_or_ctx_max_bytes(w, h, c), 64), np.uint8)
+    n = L.sicl_or_ctx_encode(_ptr(latent), _ptr(scale), w, h, c, image_wh[0], image_wh[1], _ptr(out), out.size)
+    if n < 0:
+        raise RuntimeError(f"sicl_or_ctx_encode rc={n}")
+    return out[:n].tobytes()
+
+
+def ctx_decode(container: bytes, scale: np.ndarray):
+    """Returns (latent [h][w][c], info[8]); `scale` must have the latent's shape."""
+    buf = np.frombuffer(container, np.uint8).copy()
+    scale = np.ascontiguousarray(scale, dtype=np.uint8)
+    info = np.zeros(8, np.uint32)
+    lat = np.zeros(max(scale.size, 1), np.uint8)
+    n = lib().sicl_or_ctx_decode(_ptr(buf), buf.size, _ptr(scale), _ptr(lat), scale.size, _ptr(info))
+    if n < 0:
+        raise RuntimeError(f"sicl_or_ctx_decode rc={n}")
     return lat[: int(info[6])].reshape(int(info[4]), int(info[3]), int(info[5])), info
 
 

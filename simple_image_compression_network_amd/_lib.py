@@ -104,6 +104,10 @@ CODEC_ABI = {
     "sicn_codec_decode_batch": (_i, [_vp, _sz, ctypes.POINTER(_sz), _u32, _vp, _sz, ctypes.POINTER(CodecInfo), _vp, _sz, _vp]),
     "sicn_codec_encode_batch_async": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _sz, _vp, _vp, _sz, _vp]),
     "sicn_codec_decode_batch_async": (_i, [_vp, _sz, _vp, _u32, _u32, _u32, _u32, _vp, _sz, _vp, _vp, _sz, _vp]),
+    "sicn_codec_ctx_max_bytes": (_sz, [_u32, _u32, _u32]),
+    "sicn_codec_ctx_workspace_bytes": (_sz, [_u32, _u32, _u32, _u32]),
+    "sicn_codec_ctx_encode_batch_async": (_i, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _sz, _vp, _vp, _sz, _vp]),
+    "sicn_codec_ctx_decode_batch_async": (_i, [_vp, _sz, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _sz, _vp]),
     "sicn_codec_selftest_div": (ctypes.c_longlong, [_u32, _u32, ctypes.POINTER(ctypes.c_ulonglong)]),
 }
 

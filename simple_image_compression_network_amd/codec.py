@@ -8,9 +8,9 @@ import ctypes
 
 from . import _lib
 
-RAW8, PACKED7, RANS, RANSW = 0, 1, 2, 3
-__all__ = ["RAW8", "PACKED7", "RANS", "RANSW", "encode_latent", "decode_latent", "parse_header", "encode_latents",
-           "decode_latents", "LatentCoder"]
+RAW8, PACKED7, RANS, RANSW, RANSWC = 0, 1, 2, 3, 4
+__all__ = ["RAW8", "PACKED7", "RANS", "RANSW", "RANSWC", "encode_latent", "decode_latent", "parse_header", "encode_latents",
+           "decode_latents", "LatentCoder", "ContextCoder"]
 
 
 def _stream_ptr(stream):
@@ -157,3 +157,52 @@ class LatentCoder:
             raise _lib.SicnError(-22, f"rANS-W encode status {e}")
         if any(d):
             raise _lib.SicnError(-22 if any(v & ~128 for v in d) else -74, f"rANS-W decode status {d}")
+
+
+class ContextCoder:
+    """Container mode 4 ("rANS-WC", sicn_codec_ctx_*_async): the conditional coder of the hyperprior configuration — 16
+    class tables, class from the hyper-synthesis scale map and, for the non-anchor half of a checkerboard, from the
+    already decoded anchor neighbours.  Same conventions as LatentCoder (enqueue only; verdicts / sizes on the device)."""
+
+    def __init__(self, n_images: int, lat_h: int, lat_w: int, lat_c: int, image_width: int = 0, image_height: int = 0,
+                 device="cuda"):
+        import torch
+        L = _lib.lib()
+        self.shape = (int(n_images), int(lat_h), int(lat_w), int(lat_c))
+        self.image_wh = (int(image_width), int(image_height))
+        self.slot = (int(L.sicn_codec_ctx_max_bytes(lat_w, lat_h, lat_c)) + 255) // 256 * 256
+        dev = torch.device(device)
+        self.slots = torch.empty((n_images, self.slot), dtype=torch.uint8, device=dev)
+        self.ws = torch.empty(max(L.sicn_codec_ctx_workspace_bytes(lat_w, lat_h, lat_c, n_images), 256), dtype=torch.uint8, device=dev)
+        self.enc_status = torch.zeros((n_images, 2), dtype=torch.int32, device=dev)
+        self.dec_status = torch.zeros((n_images, 2), dtype=torch.int32, device=dev)
+
+    def _check(self, t, what):
+        import torch
+        if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous() and tuple(t.shape) == self.shape):
+            raise TypeError(f"{what} must be a contiguous CUDA uint8 tensor of shape {self.shape}")
+
+    def encode(self, latents, scales, stream=None):
+        self._check(latents, "latents")
+        self._check(scales, "scales")
+        n, h, w, c = self.shape
+        _lib.check(_lib.lib().sicn_codec_ctx_encode_batch_async(
+            ctypes.c_void_p(latents.data_ptr()), ctypes.c_void_p(scales.data_ptr()), n, w, h, c, self.image_wh[0], self.image_wh[1],
+            ctypes.c_void_p(self.slots.data_ptr()), self.slot, ctypes.c_void_p(self.enc_status.data_ptr()),
+            ctypes.c_void_p(self.ws.data_ptr()), self.ws.numel(), _stream_ptr(stream)), "sicn_codec_ctx_encode_batch_async")
+        return self.slots
+
+    def decode(self, out_latents, scales, slots=None, valid=None, stream=None):
+        self._check(out_latents, "out_latents")
+        self._check(scales, "scales")
+        n, h, w, c = self.shape
+        slots = self.slots if slots is None else slots
+        vptr = None if valid is False else ctypes.c_void_p((self.enc_status if valid is None else valid).data_ptr())
+        _lib.check(_lib.lib().sicn_codec_ctx_decode_batch_async(
+            ctypes.c_void_p(slots.data_ptr()), self.slot, vptr, ctypes.c_void_p(scales.data_ptr()), n, w, h, c,
+            ctypes.c_void_p(out_latents.data_ptr()), ctypes.c_void_p(self.dec_status.data_ptr()),
+            ctypes.c_void_p(self.ws.data_ptr()), self.ws.numel(), _stream_ptr(stream)), "sicn_codec_ctx_decode_batch_async")
+        return out_latents
+
+    sizes = LatentCoder.sizes
+    check = LatentCoder.check

@@ -725,9 +725,16 @@ extern "C" int sicn_codec_parse_header(const uint8_t *h, size_t bytes, sicn_code
     info->n_streams = get32(h + 32);
     info->payload_bytes = get32(h + 40);
     info->adler32 = get32(h + 44);
-    if (info->mode > 3 || get32(h + 36) != stream_symbols((int)info->mode)) return SICN_EINVAL;
+    if (info->mode > 4 || get32(h + 36) != stream_symbols(info->mode == 4 ? 3 : (int)info->mode)) return SICN_EINVAL;
     if ((unsigned long long)info->lat_w * info->lat_h * info->lat_c != info->n_symbols) return SICN_EINVAL;
     const uint32_t ss = stream_symbols((int)info->mode);
+    if (info->mode == 4) {   // anchors and non-anchors are cut into streams separately (sicn_codec_ctx.inc)
+        const uint32_t W = info->lat_w, H = info->lat_h, C = info->lat_c;
+        const unsigned long long na = ((unsigned long long)(H / 2) * W + ((H & 1) ? (W + 1) / 2 : 0)) * C;
+        const unsigned long long nn = ((unsigned long long)(H / 2) * W + ((H & 1) ? W / 2 : 0)) * C;
+        if (info->n_streams != (na + WSS - 1) / WSS + (nn + WSS - 1) / WSS) return SICN_EINVAL;
+        return SICN_OK;
+    }
     if (info->n_streams != (info->n_symbols + ss - 1) / ss) return SICN_EINVAL;
     return SICN_OK;
 }
@@ -1051,3 +1058,5 @@ extern "C" int sicn_codec_decode_batch(const uint8_t *containers, size_t slot_by
         if (int e = status_to_rc(st[n_images + i].error)) return e;
     return SICN_OK;
 }
+
+#include "sicn_codec_ctx.inc"   // container mode 4: class-conditional rANS-W with a checkerboard context model
