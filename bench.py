@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--images-per-gpu", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-coder", action="store_true", help="skip the secondary with_coder measurement")
+    ap.add_argument("--no-hyperprior", action="store_true", help="skip the secondary hyperprior (configs[4]) measurement")
     ap.add_argument("--cpu-sample", type=int, nargs=2, default=[256, 256], metavar=("W", "H"))
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank) is the real thing; gloo lets several ranks share one GPU "
@@ -219,6 +220,34 @@ def main():
                       "path": "analysis (L0-L3) -> sicn_codec_encode_batch_async (rANS-W) -> sicn_codec_decode_batch_async -> "
                               "synthesis (L4-L7), all enqueued on one stream without host synchronisation",
                       "note": "the coder is this project's own (the reference has none); parity unpinned"}
+    # ---- secondary: BASELINE.json configs[4], the hyperprior configuration (GDN / IGDN main transform, hyper stacks,
+    # ---- mode-3 coder for the hyper-latent, mode-4 conditional coder for the latent) on the same batch -----------------
+    hyper = None
+    if not args.no_hyperprior:
+        from simple_image_compression_network_amd.hyperprior import HyperpriorCodec
+        hc = HyperpriorCodec(W, H, B, seed=0, device=dev, main_params=params)
+        out_h2 = torch.empty_like(out)
+
+        def hyper_step():    # enqueue only: g_a, h_a, z coder, h_s, y coder | z decoder, h_s, y decoder, g_s
+            hc.encode(x)
+            hc.decode(out_h2)
+
+        hyper_step()
+        hc.check()
+        hsteps = max(2, args.steps // 4)
+        hdt = timed(hyper_step, hsteps)
+        hc.check()
+        direct = torch.empty_like(out)
+        hc.main.forward(x, direct, want_latent=False)      # the same transform without the coders in between
+        hyper = {"value": round(world * B * W * H * hsteps / hdt / 1e6, 2), "unit": "Mpixels/s",
+                 "ms_per_step": round(hdt / hsteps * 1e3, 3), "steps": hsteps,
+                 "bits_per_pixel": round(8.0 * sum(hc.bytes_per_image()) / (B * W * H), 4),
+                 "round_trip_exact": bool(torch.equal(hc.y_hat, hc.y)) and bool(torch.equal(out_h2, direct)),
+                 "path": "g_a (L0-L3, GDN) -> h_a -> rANS-W(z) -> h_s -> rANS-WC(y | scale map, checkerboard context) | decode: "
+                         "rANS-W(z) -> h_s -> rANS-WC(y) -> g_s (L4-L7, IGDN); one stream, no host synchronisation",
+                 "note": "BASELINE.json configs[4]; no reference counterpart (SURVEY.md section 0): parity unpinned, seeded random "
+                         "hyper / GDN parameters"}
+        del hc, out_h2, direct
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -282,6 +311,8 @@ def main():
     }
     if with_coder is not None:
         res["with_coder"] = with_coder
+    if hyper is not None:
+        res["hyperprior"] = hyper
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(host[0], args.cpu_sample, lat_h[0], out_h[0])
     print(json.dumps(res))

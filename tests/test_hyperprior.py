@@ -1,0 +1,93 @@
+"""The hyperprior configuration (BASELINE.json configs[4]): main transform with GDN / IGDN + hyper-analysis / hyper-synthesis
+stacks + mode-3 coder for the hyper-latent + mode-4 conditional coder for the latent.  NEW functionality, parity unpinned
+(the reference has none of it).  Every stage of the GPU pipeline is held to the oracle's statement of the same
+stage: layers (closed form), GDN (sicn_gdn_oracle.c), containers (sicn_codec_oracle.c / sicn_hyper_oracle.c)."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle, sicn_ref
+
+gpu = pytest.mark.gpu
+
+
+def _cpu_layer(x, w, b, tr, gdn=None):
+    if gdn is None:
+        return sicn_ref.deconv522_ref(x, w, b) if tr else sicn_ref.conv2d_ref(x, w, b)
+    beta, gamma, inv, sh = gdn
+    return c_oracle.gdn(sicn_ref.layer_preact_ref(x, w, b, tr), beta, gamma, inv, sh)
+
+
+def test_hyper_descs_geometry():
+    from simple_image_compression_network_amd.hyperprior import hyper_descs
+    da, ds = hyper_descs(240, 135)                       # 4K latent
+    assert [d.out_shape for d in da] == [(68, 120, 128), (34, 60, 128)]
+    assert [d.out_shape for d in ds] == [(68, 120, 128), (136, 240, 192)]   # one row more than the latent: cropped
+    da, ds = hyper_descs(16, 16)
+    assert da[-1].out_shape == (4, 4, 128) and ds[-1].out_shape == (16, 16, 192)
+
+
+@gpu
+@pytest.mark.parametrize("size", [(96, 64), (176, 144), (208, 112)])   # latents 6x4, 11x9 (odd: cropped scale map), 13x7
+@pytest.mark.parametrize("use_gdn", [True, False])
+def test_gpu_hyperprior_pipeline_equals_oracle_stage_by_stage(size, use_gdn):
+    import torch
+    from simple_image_compression_network_amd.hyperprior import HyperpriorCodec
+    w, h = size
+    n = 2
+    hc = HyperpriorCodec(w, h, n, seed=7, use_gdn=use_gdn)
+    rng = np.random.default_rng(11)
+    x = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    xd = torch.from_numpy(x).cuda()
+    out = torch.empty((n,) + hc.main.descs[-1].out_shape, dtype=torch.uint8, device="cuda")
+    hc.encode(xd)
+    hc.decode(out)
+    hc.check()
+    torch.cuda.synchronize()
+    main = sicn_ref.load_param_fixture(__import__("conftest").GOLDEN / "param_weights.npz")
+    zs, ys = hc.z_coder.sizes(), hc.y_coder.sizes()
+    for i in range(n):
+        a = x[i]
+        for l in range(4):
+            a = _cpu_layer(a, main[l][0], main[l][1], 0, hc.gdn_np[l])
+        y = a
+        assert np.array_equal(hc.y[i].cpu().numpy(), y), "latent"
+        z = y
+        for (wt, bt) in hc.ha_np:
+            z = _cpu_layer(z, wt, bt, 0)
+        assert np.array_equal(hc.z[i].cpu().numpy(), z), "hyper-latent"
+        zblob = c_oracle.codec_encode(z, (w, h), 3)
+        assert hc.z_coder.slots[i, :zs[i]].cpu().numpy().tobytes() == zblob
+        s = z
+        for (wt, bt) in hc.hs_np:
+            s = _cpu_layer(s, wt, bt, 1)
+        s = np.ascontiguousarray(s[: y.shape[0], : y.shape[1]])
+        assert np.array_equal(hc.s[i].cpu().numpy(), s), "scale map"
+        yblob = c_oracle.ctx_encode(y, s, (w, h))
+        assert hc.y_coder.slots[i, :ys[i]].cpu().numpy().tobytes() == yblob
+        back, _ = c_oracle.ctx_decode(yblob, s)
+        assert np.array_equal(back, y) and np.array_equal(hc.y_hat[i].cpu().numpy(), y)
+        r = y
+        for l in range(4, 8):
+            r = _cpu_layer(r, main[l][0], main[l][1], 1, hc.gdn_np[l])
+        assert np.array_equal(out[i].cpu().numpy(), r), "reconstruction"
+    assert hc.bytes_per_image() == [a + b for a, b in zip(zs, ys)]
+
+
+@gpu
+def test_gpu_hyperprior_decoder_needs_only_the_containers():
+    """A second codec object (same seed = same weights) decodes from the two container sets alone."""
+    import torch
+    from simple_image_compression_network_amd.hyperprior import HyperpriorCodec
+    enc = HyperpriorCodec(128, 96, 1, seed=3)
+    dec = HyperpriorCodec(128, 96, 1, seed=3)
+    x = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (1, 96, 128, 3), dtype=np.uint8)).cuda()
+    zc, yc = enc.encode(x)
+    ref = torch.empty((1, 96, 128, 3), dtype=torch.uint8, device="cuda")
+    enc.decode(ref)
+    enc.check()
+    out = torch.empty_like(ref)
+    dec.z_coder.enc_status.copy_(enc.z_coder.enc_status)      # the valid-byte counts travel with the containers
+    dec.y_coder.enc_status.copy_(enc.y_coder.enc_status)
+    dec.decode(out, z_slots=zc.clone(), y_slots=yc.clone())
+    dec.check()
+    assert torch.equal(out, ref)
