@@ -94,7 +94,9 @@ typedef struct sicn_options {
     int32_t no_phase_layout; /* 0: default; 1: never use the PHASE layout; 2: not towards layer 7   */
     int32_t split_n;         /* 0: automatic; 1: never split; 2, 3, 4: output-channel split of the  */
                              /*    MFMA layers (grids smaller than the chip)                        */
-    int32_t reserved[9];
+    int32_t wave_tile;       /* 0: automatic; 64: always the 64 x 128-per-wave kernels (two waves per SIMD); 128: the  */
+                             /*    128 x 128-per-wave kernel (one wave per SIMD) wherever it exists               */
+    int32_t reserved[8];
 } sicn_options;
 
 typedef struct sicn_weights sicn_weights; /* one layer's weights+bias, resident on the device  */

@@ -49,6 +49,13 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 // `floor2`: the two 16-bit lanes the bytes are max'ed against: 0 = the reference's ReLU; ACT_FLOOR_RAW (-32768 in
 // both lanes) makes the max an identity, i.e. the lane BEFORE the ReLU (input of the GDN extension) — same instructions.
 constexpr uint32_t ACT_FLOOR_RELU = 0u, ACT_FLOOR_RAW = 0x80008000u;
+// the same kernel argument carries one more flag in a bit that is 0 in both floors: store the output non-temporal
+constexpr uint32_t ACT_NT_STORE = 1u, ACT_FLOOR_MASK = 0x80008000u;
+#ifndef SICN_NT_MIN_MB
+#define SICN_NT_MIN_MB 128
+#endif
+// outputs that cannot stay in L2 / Infinity Cache anyway (>= 128 MiB per launch) bypass them
+__host__ inline bool nt_store_wanted(size_t out_bytes) { return out_bytes >= ((size_t)SICN_NT_MIN_MB << 20); }
 __device__ __forceinline__ uint32_t pack4_relu7(int a, int b, int c, int d, uint32_t floor2 = ACT_FLOOR_RELU)
 {
     const uint32_t ab = __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x040c000cu);  // [0, a.b0, 0, b.b0]

@@ -143,11 +143,16 @@ __device__ __forceinline__ void store_tiles16(const v4i (&acc)[Geo<TX>::NC][NT16
 #pragma unroll
         for (int J = 0; J < NT16 / 4; J++) {
             v4i v;
-            v[0] = (int)pack4_relu7(acc[c][4 * J + 0][0], acc[c][4 * J + 0][1], acc[c][4 * J + 0][2], acc[c][4 * J + 0][3], act_floor);
-            v[1] = (int)pack4_relu7(acc[c][4 * J + 1][0], acc[c][4 * J + 1][1], acc[c][4 * J + 1][2], acc[c][4 * J + 1][3], act_floor);
-            v[2] = (int)pack4_relu7(acc[c][4 * J + 2][0], acc[c][4 * J + 2][1], acc[c][4 * J + 2][2], acc[c][4 * J + 2][3], act_floor);
-            v[3] = (int)pack4_relu7(acc[c][4 * J + 3][0], acc[c][4 * J + 3][1], acc[c][4 * J + 3][2], acc[c][4 * J + 3][3], act_floor);
-            __builtin_amdgcn_raw_buffer_store_b128(v, ro, ok ? off0 + (uint32_t)(2 * J) * om.grp : OOB, 0, 0);
+            v[0] = (int)pack4_relu7(acc[c][4 * J + 0][0], acc[c][4 * J + 0][1], acc[c][4 * J + 0][2], acc[c][4 * J + 0][3], act_floor & ACT_FLOOR_MASK);
+            v[1] = (int)pack4_relu7(acc[c][4 * J + 1][0], acc[c][4 * J + 1][1], acc[c][4 * J + 1][2], acc[c][4 * J + 1][3], act_floor & ACT_FLOOR_MASK);
+            v[2] = (int)pack4_relu7(acc[c][4 * J + 2][0], acc[c][4 * J + 2][1], acc[c][4 * J + 2][2], acc[c][4 * J + 2][3], act_floor & ACT_FLOOR_MASK);
+            v[3] = (int)pack4_relu7(acc[c][4 * J + 3][0], acc[c][4 * J + 3][1], acc[c][4 * J + 3][2], acc[c][4 * J + 3][3], act_floor & ACT_FLOOR_MASK);
+            // outputs far larger than the caches are stored non-temporal (aux bit 1): measured on 8 x 4K (A/B in one process,
+            // profiles/r02_ab_nt_stores.txt) layer 6 -6 % and — its consumer finds less of its own input evicted — layer 7 -8 %
+            if (act_floor & ACT_NT_STORE)
+                __builtin_amdgcn_raw_buffer_store_b128(v, ro, ok ? off0 + (uint32_t)(2 * J) * om.grp : OOB, 0, 2);
+            else
+                __builtin_amdgcn_raw_buffer_store_b128(v, ro, ok ? off0 + (uint32_t)(2 * J) * om.grp : OOB, 0, 0);
         }
     }
 }
@@ -381,7 +386,7 @@ static hipError_t launch16_tx(const LayerGeom &g, const sicn_weights &w, const u
     dim3 grid(xcd_grid_size(tiles_x * tiles_y * n_images));
     hipLaunchKernelGGL((k_mfma16_t<NQ, NT16, DECONV, MINW, TX>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias,
                        g.IW, g.IH, g.OW, g.OH, MW, MH, tiles_x, tiles_x * tiles_y, n_images, in_layout, out_layout,
-                       relu ? ACT_FLOOR_RELU : ACT_FLOOR_RAW);
+                       (relu ? ACT_FLOOR_RELU : ACT_FLOOR_RAW) | (nt_store_wanted((size_t)g.OH * g.OW * g.COUT * n_images) ? ACT_NT_STORE : 0u));
     return hipGetLastError();
 }
 
@@ -397,6 +402,11 @@ static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint
     bool narrow = minw16(NQ, NT16, 32) == 1 || tiles32 < 2 * 256;
     if (o.tile_x == 16) narrow = true;
     if (o.tile_x == 32) narrow = false;
+    // layers 1 / 2 (conv 128 -> 128): the wide form (one wave per SIMD, 128 x 128 tile per wave, k_mfma16w.hip) is bit-exact but
+    // measured 8 % SLOWER than this file's kernels on 8 x 4K (its per-tile prologue / epilogue has no partner wave to hide
+    // behind): opt-in only (sicn_options.wave_tile = 128)
+    if constexpr (!DECONV && NQ == 4 && NT16 == 8)
+        if (!narrow && o.wave_tile == 128) return launch_conv128w(g, w, in, out, n_images, stream, in_layout, out_layout, relu);
     return narrow ? launch16_tx<NQ, NT16, DECONV, 16>(g, w, in, out, n_images, stream, in_layout, out_layout, relu)
                   : launch16_tx<NQ, NT16, DECONV, 32>(g, w, in, out, n_images, stream, in_layout, out_layout, relu);
 }
@@ -420,7 +430,10 @@ hipError_t launch_mfma16(const LayerGeom &g, const sicn_weights &w, const uint8_
 
 // ---- host-side weight packing: the same tile sequence as pack_mfma_stream, rows in the 16x16 C/D
 // ---- order (LDS row j*16 + rho holds channel 64*(j>>2) + 16*(rho>>2) + 4*(j&3) + (rho&3)), no swizzle
-size_t mfma16_stream_bytes(int cin, int cout) { return (size_t)(25 * (cin / 32) + PF16) * cout * KSTEP; }
+// zero tiles behind the stream: the deepest prefetch of any kernel that walks it (k_mfma16: PF16 = 6, k_mfma16w: 8)
+constexpr int PAD16 = 8;
+static_assert(PAD16 >= PF16, "prefetch would run off the stream");
+size_t mfma16_stream_bytes(int cin, int cout) { return (size_t)(25 * (cin / 32) + PAD16) * cout * KSTEP; }
 
 static void pack_tile16(const int8_t *w_okc, int cin, int cout, int tap, int q, int8_t *tile)
 {
@@ -454,7 +467,7 @@ void pack_mfma16_stream(const int8_t *w_okc, int cin, int cout, int transposed, 
                 }
         }
     }
-    for (size_t i = step * tb; i < (step + PF16) * tb; i++) dst[i] = 0;
+    for (size_t i = step * tb; i < (step + PAD16) * tb; i++) dst[i] = 0;
 }
 
 }  // namespace sicn

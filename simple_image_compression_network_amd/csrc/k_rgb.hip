@@ -180,12 +180,17 @@ __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, u
             for (int j = 0; j < NTJ; j++) {
                 const v16i a = acc[i][j];
                 v4i v;
-                v[0] = (int)pack4_relu7(a[0], a[1], a[2], a[3], act_floor);
-                v[1] = (int)pack4_relu7(a[4], a[5], a[6], a[7], act_floor);
-                v[2] = (int)pack4_relu7(a[8], a[9], a[10], a[11], act_floor);
-                v[3] = (int)pack4_relu7(a[12], a[13], a[14], a[15], act_floor);
+                v[0] = (int)pack4_relu7(a[0], a[1], a[2], a[3], act_floor & ACT_FLOOR_MASK);
+                v[1] = (int)pack4_relu7(a[4], a[5], a[6], a[7], act_floor & ACT_FLOOR_MASK);
+                v[2] = (int)pack4_relu7(a[8], a[9], a[10], a[11], act_floor & ACT_FLOOR_MASK);
+                v[3] = (int)pack4_relu7(a[12], a[13], a[14], a[15], act_floor & ACT_FLOOR_MASK);
                 const uint32_t off = ok ? tensor_offset(om, gy, gx, (uint32_t)j) + 16u * kh : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(v, ro, off, 0, 0);
+#ifdef SICN_L0_NT
+                if (act_floor & ACT_NT_STORE)
+                    __builtin_amdgcn_raw_buffer_store_b128(v, ro, off, 0, 2);
+                else
+#endif
+                    __builtin_amdgcn_raw_buffer_store_b128(v, ro, off, 0, 0);
             }
         }
         block_barrier();  // next patch complete, this patch free (raw barrier: the stores stay in flight)
@@ -235,7 +240,8 @@ hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
         hipError_t e = hipFuncSetAttribute((const void *)k_l0<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_l0<4>, grid, dim3(256), lds, stream, in, out, w.d_w_l0, w.d_bias, g.IW, g.IH,
-                           g.OW, g.OH, tiles_y, ty_per, out_layout, relu ? ACT_FLOOR_RELU : ACT_FLOOR_RAW);
+                           g.OW, g.OH, tiles_y, ty_per, out_layout,
+                           (relu ? ACT_FLOOR_RELU : ACT_FLOOR_RAW) | (nt_store_wanted((size_t)g.OH * g.OW * g.COUT * n_images) ? ACT_NT_STORE : 0u));
     } else
         return hipErrorInvalidValue;
     return hipGetLastError();

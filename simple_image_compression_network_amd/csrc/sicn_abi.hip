@@ -33,6 +33,7 @@ const sicn_options &default_options()
         d.strip_chunks = env_int("SICN_STRIP_CHUNKS");
         d.no_phase_layout = env_int("SICN_NO_PHASE_LAYOUT");
         d.split_n = env_int("SICN_SPLIT_N");
+        d.wave_tile = env_int("SICN_WAVE_TILE");
         return d;
     }();
     return o;
@@ -58,6 +59,7 @@ static int resolve_options(const sicn_options *in, sicn_options *out)
     if (o.tile_x != 0 && o.tile_x != 16 && o.tile_x != 32) return SICN_EINVAL;
     if (o.strip_chunks < 0 || o.no_phase_layout < 0 || o.no_phase_layout > 2) return SICN_EINVAL;
     if (o.split_n < 0 || o.split_n > 4) return SICN_EINVAL;
+    if (o.wave_tile != 0 && o.wave_tile != 64 && o.wave_tile != 128) return SICN_EINVAL;
     *out = o;
     return SICN_OK;
 }
