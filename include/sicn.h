@@ -96,7 +96,9 @@ typedef struct sicn_options {
                              /*    MFMA layers (grids smaller than the chip)                        */
     int32_t wave_tile;       /* 0: automatic; 64: always the 64 x 128-per-wave kernels (two waves per SIMD); 128: the  */
                              /*    128 x 128-per-wave kernel (one wave per SIMD) wherever it exists               */
-    int32_t reserved[8];
+    int32_t prefetch;        /* 0: automatic; 1: never, 2: wherever it exists — the software-pipelined kernels         */
+                             /*    (fragments double-buffered in AGPRs, k_mfma16p.hip)                                 */
+    int32_t reserved[7];
 } sicn_options;
 
 typedef struct sicn_weights sicn_weights; /* one layer's weights+bias, resident on the device  */

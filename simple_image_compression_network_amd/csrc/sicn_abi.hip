@@ -34,6 +34,7 @@ const sicn_options &default_options()
         d.no_phase_layout = env_int("SICN_NO_PHASE_LAYOUT");
         d.split_n = env_int("SICN_SPLIT_N");
         d.wave_tile = env_int("SICN_WAVE_TILE");
+        d.prefetch = env_int("SICN_PREFETCH");
         return d;
     }();
     return o;
@@ -60,6 +61,7 @@ static int resolve_options(const sicn_options *in, sicn_options *out)
     if (o.strip_chunks < 0 || o.no_phase_layout < 0 || o.no_phase_layout > 2) return SICN_EINVAL;
     if (o.split_n < 0 || o.split_n > 4) return SICN_EINVAL;
     if (o.wave_tile != 0 && o.wave_tile != 64 && o.wave_tile != 128) return SICN_EINVAL;
+    if (o.prefetch < 0 || o.prefetch > 2) return SICN_EINVAL;
     *out = o;
     return SICN_OK;
 }

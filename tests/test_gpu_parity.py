@@ -159,7 +159,7 @@ def test_wide_wave_tile_conv_matches_oracle(api, case, wave_tile):
     W, b, words = _rand_params(rng, d)
     x = rng.integers(0, 128, (3,) + d.in_shape, dtype=np.uint8)
     x[0].reshape(-1)[::7] |= 0x80
-    got = _run_layer(api, d, words, b, x, tile_x=32, wave_tile=wave_tile)
+    got = _run_layer(api, d, words, b, x, tile_x=32, wave_tile=wave_tile, prefetch=1)
     for i in range(3):
         assert np.array_equal(got[i], sicn_ref.conv2d_ref(x[i], W, b)), (i, np.count_nonzero(got[i] != sicn_ref.conv2d_ref(x[i], W, b)))
 
@@ -167,7 +167,38 @@ def test_wide_wave_tile_conv_matches_oracle(api, case, wave_tile):
 @pytest.mark.parametrize("wave_tile", [64, 128])
 def test_wide_wave_tile_in_chain(api, wave_tile):
     xin = _dev(_input("rng768")[None])
-    net = api.EightLayersNet(768, 512, options={"tile_x": 32, "wave_tile": wave_tile})
+    net = api.EightLayersNet(768, 512, options={"tile_x": 32, "wave_tile": wave_tile, "prefetch": 1})
+    out, latent = net.forward(xin)
+    torch.cuda.synchronize()
+    assert _sha(out[0].cpu().numpy()) == HASHES["layers"]["rng768"][7]
+    assert _sha(latent[0].cpu().numpy()) == HASHES["layers"]["rng768"][3]
+
+
+PIPE_CASES = [(128, 128, 8, 16, 34, 10, 1), (128, 128, 8, 16, 1, 1, 1), (128, 128, 8, 16, 65, 19, 1), (128, 128, 8, 16, 100, 45, 1),
+              (128, 128, 4, 32, 33, 17, 1)]
+
+
+@pytest.mark.parametrize("prefetch", [1, 2])
+@pytest.mark.parametrize("case", PIPE_CASES + WIDE_CASES)
+def test_pipelined_kernels_match_oracle(api, case, prefetch):
+    """conv / deconv 128 -> 128 exist as k_mfma16.hip's kernels (prefetch = 1) and as the software-pipelined k_mfma16p.hip
+    (prefetch = 2, the default on full-size grids): force each, with the wide tile, on odd sizes / single pixels / several
+    tiles / high-bit inputs."""
+    rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + prefetch)
+    d = _mk_desc(*case)
+    W, b, words = _rand_params(rng, d)
+    x = rng.integers(0, 128, (3,) + d.in_shape, dtype=np.uint8)
+    x[0].reshape(-1)[::7] |= 0x80
+    got = _run_layer(api, d, words, b, x, tile_x=32, prefetch=prefetch)
+    for i in range(3):
+        ref = (sicn_ref.deconv522_ref if d.transposed else sicn_ref.conv2d_ref)(x[i], W, b)
+        assert np.array_equal(got[i], ref), (i, np.count_nonzero(got[i] != ref))
+
+
+@pytest.mark.parametrize("prefetch", [1, 2])
+def test_pipelined_kernels_in_chain(api, prefetch):
+    xin = _dev(_input("rng768")[None])
+    net = api.EightLayersNet(768, 512, options={"tile_x": 32, "prefetch": prefetch})
     out, latent = net.forward(xin)
     torch.cuda.synchronize()
     assert _sha(out[0].cpu().numpy()) == HASHES["layers"]["rng768"][7]
