@@ -402,11 +402,13 @@ static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint
     bool narrow = minw16(NQ, NT16, 32) == 1 || tiles32 < 2 * 256;
     if (o.tile_x == 16) narrow = true;
     if (o.tile_x == 32) narrow = false;
-    // layers 5 / 6 (deconv 128 -> 128) on full-size grids: the software-pipelined form (fragments in AGPRs, k_mfma16p.hip)
-    if constexpr (DECONV && NQ == 4 && NT16 == 8)
-        if (!narrow && o.prefetch != 1) return launch_deconv128p(g, w, in, out, n_images, stream, in_layout, out_layout, relu);
-    if constexpr (!DECONV && NQ == 4 && NT16 == 8)
-        if (!narrow && o.prefetch != 1 && o.wave_tile != 128) return launch_conv128p(g, w, in, out, n_images, stream, in_layout, out_layout, relu);
+    // the software-pipelined form of the same kernels (k_mfma16p.hip) is the default wherever it exists
+    {
+        const int tx = narrow ? 16 : 32;
+        const bool wide_asked = !DECONV && NQ == 4 && NT16 == 8 && !narrow && o.wave_tile == 128;
+        if (o.prefetch != 1 && !wide_asked && pipelined_supported(g, tx))
+            return launch_pipelined(g, w, in, out, n_images, stream, in_layout, out_layout, relu, tx);
+    }
     // layers 1 / 2 (conv 128 -> 128): the wide form (one wave per SIMD, 128 x 128 tile per wave, k_mfma16w.hip) is bit-exact but
     // measured 8 % SLOWER than this file's kernels on 8 x 4K (its per-tile prologue / epilogue has no partner wave to hide
     // behind): opt-in only (sicn_options.wave_tile = 128)

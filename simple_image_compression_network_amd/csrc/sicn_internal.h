@@ -69,11 +69,10 @@ hipError_t launch_mfma16(const LayerGeom &g, const sicn_weights &w, const uint8_
 // k_mfma16w.hip: conv 128 -> 128 with a 128 x 128 output tile per wave (accumulators in AGPRs, one wave per SIMD)
 hipError_t launch_conv128w(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
                            hipStream_t stream, int in_layout, int out_layout, bool relu);
-// k_mfma16p.hip: deconv 128 -> 128 with double-buffered fragments in AGPRs and hand-placed prefetch
-hipError_t launch_conv128p(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
-                           hipStream_t stream, int in_layout, int out_layout, bool relu);
-hipError_t launch_deconv128p(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
-                             hipStream_t stream, int in_layout, int out_layout, bool relu);
+// k_mfma16p.hip: the software-pipelined conv / deconv kernels (tile_x = 16 | 32)
+bool pipelined_supported(const LayerGeom &g, int tile_x);
+hipError_t launch_pipelined(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
+                            hipStream_t stream, int in_layout, int out_layout, bool relu, int tile_x);
 hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
                      int n_images, hipStream_t stream, int out_layout, const sicn_options &o, bool relu = true);
 hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,

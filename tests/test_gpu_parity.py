@@ -129,16 +129,20 @@ def test_32x32x32_kernels_match_oracle(api, case):
         assert np.array_equal(got[i], ref_fn(x[i], W, b))
 
 
+@pytest.mark.parametrize("prefetch", [1, 2])
 @pytest.mark.parametrize("tile_x", ["16", "32"])
-@pytest.mark.parametrize("case", MFMA_CASES + [(128, 128, 8, 16, 50, 20, 0), (192, 128, 12, 16, 37, 21, 1), (128, 192, 8, 24, 47, 18, 0)])
-def test_both_tile_widths_match_oracle(api, case, tile_x):
-    """The 16x16x64 kernels exist for 8 x 32 and 8 x 16 position tiles (the launcher picks by layer shape and
-    grid size); force each one on every shape."""
+@pytest.mark.parametrize("case", MFMA_CASES + [(128, 128, 8, 16, 50, 20, 0), (192, 128, 12, 16, 37, 21, 1), (128, 192, 8, 24, 47, 18, 0),
+                                  (192, 128, 12, 16, 45, 19, 0), (128, 192, 8, 24, 21, 13, 1), (192, 128, 12, 16, 9, 40, 0)])
+def test_both_tile_widths_match_oracle(api, case, tile_x, prefetch):
+    """The 16x16x64 kernels exist for 8 x 32 and 8 x 16 position tiles (the launcher picks by layer shape and grid size) and
+    in a plain (k_mfma16.hip) and a software-pipelined form (k_mfma16p.hip, the default wherever it exists: every shape at
+    8 x 16, the 128 -> 128 shapes also at 8 x 32); force each combination on every shape, incl. the hyperprior stacks'
+    conv 192 -> 128 and deconv 128 -> 192."""
     rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + int(tile_x))
     d = _mk_desc(*case)
     W, b, words = _rand_params(rng, d)
     x = rng.integers(0, 128, (2,) + d.in_shape, dtype=np.uint8)
-    got = _run_layer(api, d, words, b, x, tile_x=int(tile_x))
+    got = _run_layer(api, d, words, b, x, tile_x=int(tile_x), prefetch=prefetch)
     ref_fn = sicn_ref.deconv522_ref if d.transposed else sicn_ref.conv2d_ref
     for i in range(2):
         assert np.array_equal(got[i], ref_fn(x[i], W, b))
