@@ -42,7 +42,7 @@ sys.path.insert(0, str(ROOT))
 
 PEAK_INT8_TOPS = 5000.0   # dense int8 MFMA = 2x the ~2.5 PFLOP/s bf16 dense peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0     # HBM3E spec
-KERNEL_SOURCES = ("k_common.hpp", "k_mfma16.hip", "k_mfma.hip", "k_rgb.hip", "k_generic.hip", "sicn_abi.hip")
+KERNEL_SOURCES = ("k_common.hpp", "k_mfma16.hip", "k_mfma16p.hip", "k_mfma16w.hip", "k_mfma.hip", "k_rgb.hip", "k_generic.hip", "sicn_abi.hip")
 
 
 def kernel_source_fingerprint() -> str:

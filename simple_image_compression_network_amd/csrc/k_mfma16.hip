@@ -437,8 +437,8 @@ hipError_t launch_mfma16(const LayerGeom &g, const sicn_weights &w, const uint8_
 
 // ---- host-side weight packing: the same tile sequence as pack_mfma_stream, rows in the 16x16 C/D
 // ---- order (LDS row j*16 + rho holds channel 64*(j>>2) + 16*(rho>>2) + 4*(j&3) + (rho&3)), no swizzle
-// zero tiles behind the stream: the deepest prefetch of any kernel that walks it (k_mfma16: PF16 = 6, k_mfma16w: 8)
-constexpr int PAD16 = 8;
+// zero tiles behind the stream: the deepest prefetch of any kernel that walks it (k_mfma16: PF16 = 6, k_mfma16w: 8, k_mfma16p: 12)
+constexpr int PAD16 = 12;
 static_assert(PAD16 >= PF16, "prefetch would run off the stream");
 size_t mfma16_stream_bytes(int cin, int cout) { return (size_t)(25 * (cin / 32) + PAD16) * cout * KSTEP; }
 

@@ -23,13 +23,21 @@
 
 namespace sicn {
 
-constexpr int PFP = 8;    // weight tiles (K steps) requested ahead of the MFMAs that use them: 4 passes
-constexpr int RINGP = 8;  // the tile requested in pass k overwrites the slot whose fragments pass k - 1 finished reading
-static_assert(RINGP == PFP, "ring slot reuse");
+// PF = weight tiles (K steps) requested ahead of the MFMAs that use them = ring slots (the tile requested in pass k overwrites
+// the slot whose fragments pass k - 1 finished reading).  The fetch for pass k+1 runs in pass k, so a tile must have landed at
+// the barrier that ends pass k - 1: requested in pass k + 1 - PF/2, it has PF/2 - 2 passes of flight time, and that many passes'
+// requests may still be in flight at a barrier.  PF = 8 (2 passes) where LDS is tight; 12 (4 passes) for the 8 x 16 tiles of
+// the 128-channel shapes, whose passes are only 16 MFMAs long — shorter than an L2 round trip.
+template <int PF>
+struct Ring {
+    static constexpr int SLOTS = PF, FLIGHT = PF / 2 - 2;
+    static_assert(PF % 2 == 0 && FLIGHT >= 1, "");
+};
 
 #define SICN_MFMA_V(ACC, A, B) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
 #define SICN_MFMA_V_C(ACC, A, B, C) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %3" : "=&v"(ACC) : "v"(A), "v"(B), "v"(C))
 
+constexpr int PAD_TILES_P = 12;   // zero tiles behind a weight stream (k_mfma16.hip: PAD16)
 template <int NT16>
 struct WTile {
     static constexpr int TB = NT16 * 16 * KSTEP;     // 4096 / 6144 bytes
@@ -37,12 +45,12 @@ struct WTile {
     static constexpr int WR = (NPB + 3) / 4;         // LDS-DMA instructions per wave and tile: 1 / 2
 };
 
-template <int NT16>
+template <int NT16, int PF>
 __device__ __forceinline__ void load_wtile_p(uint8_t *ring, const int8_t *wstream, int tile, int lane, int w)
 {
     constexpr int TB = WTile<NT16>::TB, NPB = WTile<NT16>::NPB, WR = WTile<NT16>::WR;
     const int8_t *src = wstream + (size_t)tile * TB + lane * 16;
-    uint8_t *dst = ring + (tile % RINGP) * TB;
+    uint8_t *dst = ring + (tile % PF) * TB;
 #pragma unroll
     for (int r = 0; r < WR; r++) {
         int piece = r * 4 + w;
@@ -51,17 +59,31 @@ __device__ __forceinline__ void load_wtile_p(uint8_t *ring, const int8_t *wstrea
     }
 }
 
-// One pass: NC * NT16 MFMAs (weight tile j outer, the wave's NC column tiles inner) on the weight fragments `wf` and the
-// CURRENT pixel fragments `pc`; the fragments of the NEXT pass are fetched in between: weight fragment j is re-read into its
-// own registers right after its MFMAs, pixel fragment j (j < NC) goes to the other buffer `pn`.  Then counted wait + barrier.
+// One pass: NC * NT16 MFMAs (weight tile j outer, the wave's NC column tiles inner) on the CURRENT fragments (wc, pc); the
+// fragments of the NEXT pass are fetched in between.
+//   TX = 32 (32 MFMAs per pass, registers tight): weight fragment j is re-read INTO ITS OWN registers right after its MFMAs
+//            (wn aliases wc); only the pixel fragments have a second buffer.  The last re-read is issued behind the last
+//            MFMA group, so the barrier's lgkmcnt(0) exposes one LDS round trip per pass.
+//   TX = 16 (16-24 MFMAs per pass, registers to spare): the weight fragments are double-buffered too and all reads are
+//            issued two per MFMA group from the start of the pass — on small grids a CU holds one workgroup and nothing
+//            else would hide that round trip.  (Measured worth only 2-5 % on 1080p: the small-grid passes are bound by
+//            something else — the barrier among waves that have no partner workgroup; kept because it is free.)
 //   FIRST: the accumulators start here, C operand = the bias (bias4[J] = this lane's 16 bias bytes of weight tiles 4J..4J+3)
 //   dma(): this pass's LDS-DMA requests, issued behind the first MFMA group (their targets are free for the whole pass)
-template <int TX, int NT16, int VMCNT, int EXTRA, bool FIRST, typename Dma>
-__device__ __forceinline__ void pass_p(v4i (&acc)[Geo<TX>::NC][NT16], v4i (&wf)[NT16], const v4i (&pc)[Geo<TX>::NC],
+template <int TX, int NT16, int VMCNT, int EXTRA, bool FIRST, bool WDB, typename Dma>
+__device__ __forceinline__ void pass_p(v4i (&acc)[Geo<TX>::NC][NT16], const v4i (&wc)[NT16], v4i (&wn)[NT16], const v4i (&pc)[Geo<TX>::NC],
                                        v4i (&pn)[Geo<TX>::NC], const uint8_t *pix_next, const uint8_t *wt_next, bool extra,
                                        const v4i (&bias4)[NT16 / 4], Dma dma)
 {
     constexpr int PX = Geo<TX>::PX, NC = Geo<TX>::NC, XT = Geo<TX>::XT;
+    // WDB: weights double-buffered (wn != wc)
+    auto fetch = [&](auto r_tag) {           // read number r of the next pass: the NC pixel fragments first, then the weights
+        constexpr int r = decltype(r_tag)::value;
+        if constexpr (r < NC)
+            pn[r] = *(const v4i *)(pix_next + ((r / XT) * PX + (r % XT) * 16) * 32);
+        else if constexpr (r < NC + NT16)
+            wn[r - NC] = *(const v4i *)(wt_next + (r - NC) * 16 * 32);
+    };
 #pragma unroll
     for (int j = 0; j < NT16; j++) {
         v4i cin;
@@ -75,17 +97,29 @@ __device__ __forceinline__ void pass_p(v4i (&acc)[Geo<TX>::NC][NT16], v4i (&wf)[
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             if constexpr (FIRST)
-                SICN_MFMA_V_C(acc[c][j], wf[j], pc[c], cin);
+                SICN_MFMA_V_C(acc[c][j], wc[j], pc[c], cin);
             else
-                SICN_MFMA_V(acc[c][j], wf[j], pc[c]);
+                SICN_MFMA_V(acc[c][j], wc[j], pc[c]);
         }
         // An MFMA reads its C operand a few cycles AFTER it issues, and hipcc cannot see through the asm that `cin` is an
         // MFMA operand: any VALU write into those 4 registers right behind the group (the next group's unpacking, address
         // arithmetic of the next pass) would be a write-after-read hazard.  This statement keeps `cin` live — so its registers
         // cannot be given away earlier — and spends the wait states.
         if constexpr (FIRST) asm volatile("s_nop 7" ::"v"(cin));
-        wf[j] = *(const v4i *)(wt_next + j * 16 * 32);
-        if (j < NC) pn[j] = *(const v4i *)(pix_next + ((j / XT) * PX + (j % XT) * 16) * 32);
+        if constexpr (WDB) {
+            // two reads per group: (2j, 2j+1) of [pixel 0..NC-1, weight 0..NT16-1]
+            switch (j) {
+#define SICN_F(J) case J: fetch(std::integral_constant<int, 2 * J>{}); fetch(std::integral_constant<int, 2 * J + 1>{}); break;
+                SICN_F(0) SICN_F(1) SICN_F(2) SICN_F(3) SICN_F(4) SICN_F(5) SICN_F(6) SICN_F(7) SICN_F(8) SICN_F(9) SICN_F(10) SICN_F(11)
+#undef SICN_F
+            }
+        } else {
+            switch (j) {   // in place: weight j (dead now), plus pixel fragment j while there are any
+#define SICN_F(J) case J: fetch(std::integral_constant<int, NC + J>{}); if (J < NC) fetch(std::integral_constant<int, (J < NC ? J : 0)>{}); break;
+                SICN_F(0) SICN_F(1) SICN_F(2) SICN_F(3) SICN_F(4) SICN_F(5) SICN_F(6) SICN_F(7) SICN_F(8) SICN_F(9) SICN_F(10) SICN_F(11)
+#undef SICN_F
+            }
+        }
         if (j == 0) dma();
     }
     if (EXTRA > 0 && extra)
@@ -146,7 +180,7 @@ __device__ __forceinline__ TileCoord tile_coord(int tiles_x, int n_tiles, int n_
 // =====================================================================================================================
 // deconv522<>: NQ / 2 passes per tap (channel pairs q, q+1 of one tap), the tap loop stays a loop
 // =====================================================================================================================
-template <int NQ, int NT16, int TX>
+template <int NQ, int NT16, int TX, int PF>
 __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                      const int8_t *__restrict__ wstream, const int8_t *__restrict__ bias, int IW, int IH,
                                                      int OW, int OH, int tiles_x, int n_tiles, int n_images, int in_layout,
@@ -156,7 +190,8 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
     constexpr int PX = Geo<TX>::PX, ALLOC = Geo<TX>::ALLOC, SLOTS = Geo<TX>::SLOTS;
     constexpr int TB = WTile<NT16>::TB, WR = WTile<NT16>::WR;
     constexpr int NSTORE = NC * NT16 / 4;            // output stores per wave and phase
-    constexpr int VM = 2 * 2 * WR;                   // requests of this pass and the previous one
+    constexpr int FL = Ring<PF>::FLIGHT;
+    constexpr int VM = FL * 2 * WR;                  // requests of the last FL passes
     constexpr int BIAS_LDS = (Geo<TX>::PIX * KSTEP + 1023) / 1024 * 1024;   // the padding pieces behind sub-patch 0's positions
     static_assert(BIAS_LDS + COUT <= ALLOC, "no room for the bias behind the patch");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -186,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
             load_piece<ALLOC>(patch, in_img, in_img_bytes, sub, slot * 4 + w, ps.ok ? ps.off + (uint32_t)sub * im.grp : OOB);
     }
 #pragma unroll
-    for (int s = 0; s < PFP; s++) load_wtile_p<NT16>(ring, wstream, s, lane, w);
+    for (int s = 0; s < PF; s++) load_wtile_p<NT16, PF>(ring, wstream, s, lane, w);
     // the bias goes to LDS (padding behind sub-patch 0): reading it from global memory at the start of every phase would make
     // hipcc drain vmcnt there, i.e. wait for the previous phase's stores
     uint32_t bias_dw = 0;
@@ -199,12 +234,15 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
     // a pass covers steps (s0, s0 + 1) = channel groups (q, q + 1) of one tap: fragments at
     //   pixel : lane_pix + tap offset + q * ALLOC            (the lane's K half already selects sub-patch q + hi)
     //   weight: lane_wt + ((s0 + hi) % RINGP) * TB
-    v4i wf[NT16], pbuf[2][NC];
+    // weight fragment buffers (pass_p); with an odd number of passes per tap the buffer parity is a run-time value and the
+    // second weight set costs more registers than there are (256 + scratch, layer 4 +25 %): in place there
+    constexpr int NWB = (TX == 16 && PPT % 2 == 0) ? 2 : 1;
+    v4i wbuf[NWB][NT16], pbuf[2][NC];
     v4i acc[NC][NT16];
     int step = 0;
     {   // fragments of the first pass: phase 0, tap 0 (offset 0), q = 0, steps 0 / 1
 #pragma unroll
-        for (int r = 0; r < NT16; r++) wf[r] = *(const v4i *)(lane_wt + hi * TB + r * 16 * 32);
+        for (int r = 0; r < NT16; r++) wbuf[0][r] = *(const v4i *)(lane_wt + hi * TB + r * 16 * 32);
 #pragma unroll
         for (int r = 0; r < NC; r++) pbuf[0][r] = *(const v4i *)(lane_pix + ((r / Geo<TX>::XT) * PX + (r % Geo<TX>::XT) * 16) * 32);
     }
@@ -216,24 +254,26 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
             const int q = 2 * qi, s0 = step + q;
             const bool last = qi + 1 == PPT;
             const uint8_t *pixn = lane_pix + (last ? toff_next : toff + (uint32_t)((q + 2) * ALLOC));
-            const uint8_t *wtn = lane_wt + (uint32_t)(((s0 + 2 + hi) % RINGP) * TB);
+            const uint8_t *wtn = lane_wt + (uint32_t)(((s0 + 2 + hi) % PF) * TB);
             auto dma = [&]() {
-                load_wtile_p<NT16>(ring, wstream, s0 + PFP, lane, w);
-                load_wtile_p<NT16>(ring, wstream, s0 + 1 + PFP, lane, w);
+                load_wtile_p<NT16, PF>(ring, wstream, s0 + PF, lane, w);
+                load_wtile_p<NT16, PF>(ring, wstream, s0 + 1 + PF, lane, w);
             };
-            // the previous phase's NSTORE stores are younger than the tiles awaited in the first two passes of a phase: they
+            // the previous phase's NSTORE stores are younger than the tiles awaited in the first FL passes of a phase: they
             // are counted, not waited for
-            const bool extra = ph > 0 && t == 0 && qi < 2;
+            const bool extra = ph > 0 && (t * PPT + qi) < FL;
             v4i(&pc)[NC] = pbuf[(PAR + qi) & 1];
             v4i(&pn)[NC] = pbuf[(PAR + qi + 1) & 1];
+            v4i(&wc)[NT16] = wbuf[(PAR + qi) & (NWB - 1)];
+            v4i(&wn)[NT16] = wbuf[(PAR + qi + 1) & (NWB - 1)];
             if (qi == 0 && t == 0) {
                 v4i bias4[NT16 / 4];
 #pragma unroll
                 for (int J = 0; J < NT16 / 4; J++) bias4[J] = *(const v4i *)(patch + BIAS_LDS + 64 * J + 16 * g);
-                pass_p<TX, NT16, VM, NSTORE, true>(acc, wf, pc, pn, pixn, wtn, extra, bias4, dma);
+                pass_p<TX, NT16, VM, NSTORE, true, NWB == 2>(acc, wc, wn, pc, pn, pixn, wtn, extra, bias4, dma);
             } else {
                 const v4i none[NT16 / 4] = {};
-                pass_p<TX, NT16, VM, NSTORE, false>(acc, wf, pc, pn, pixn, wtn, extra, none, dma);
+                pass_p<TX, NT16, VM, NSTORE, false, NWB == 2>(acc, wc, wn, pc, pn, pixn, wtn, extra, none, dma);
             }
         }
         step += NQ;
@@ -294,6 +334,13 @@ __host__ __device__ constexpr int conv_requests_p(int P)   // LDS-DMA instructio
     if (P < 0) return 0;
     return 2 * WTile<NT16>::WR + (refresh_plane_p((2 * P) % 25, Geo<TX>::SLOTS) >= 0) + (refresh_plane_p((2 * P + 1) % 25, Geo<TX>::SLOTS) >= 0);
 }
+template <int TX, int NT16>
+__host__ __device__ constexpr int conv_in_flight_p(int P, int n)   // requests of passes P, P-1, .. (n of them)
+{
+    int s = 0;
+    for (int i = 0; i < n; i++) s += conv_requests_p<TX, NT16>(P - i);
+    return s;
+}
 
 struct ConvPCtx {
     uint8_t *patch, *ring;
@@ -305,9 +352,10 @@ struct ConvPCtx {
     int lane, w, hi;
 };
 
-template <int TX, int NT16, int P, int NPASS>
-__device__ __forceinline__ void conv_pass_p(v4i (&acc)[Geo<TX>::NC][NT16], v4i (&wf)[NT16], const v4i (&pc)[Geo<TX>::NC],
-                                            v4i (&pn)[Geo<TX>::NC], const ConvPCtx &c, const uint32_t (&poff)[4][Geo<TX>::SLOTS])
+template <int TX, int NT16, int PF, int P, int NPASS>
+__device__ __forceinline__ void conv_pass_p(v4i (&acc)[Geo<TX>::NC][NT16], const v4i (&wc)[NT16], v4i (&wn)[NT16],
+                                            const v4i (&pc)[Geo<TX>::NC], v4i (&pn)[Geo<TX>::NC], const ConvPCtx &c,
+                                            const uint32_t (&poff)[4][Geo<TX>::SLOTS])
 {
     constexpr int ALLOC = Geo<TX>::ALLOC, S = Geo<TX>::SLOTS, TB = WTile<NT16>::TB;
     constexpr int tA = (2 * P) % 25, tB = (2 * P + 1) % 25, qA = (2 * P) / 25, qB = (2 * P + 1) / 25;
@@ -319,30 +367,32 @@ __device__ __forceinline__ void conv_pass_p(v4i (&acc)[Geo<TX>::NC][NT16], v4i (
         if constexpr (rpB >= 0)
             load_piece<ALLOC>(c.patch, c.in_img, c.in_img_bytes, rpB, refresh_slot_p(tB, S) * 4 + c.w,
                               poff[rpB][refresh_slot_p(tB, S)] + (uint32_t)((rpB == 3) ? qB : qB + 1) * c.qstride);
-        load_wtile_p<NT16>(c.ring, c.wstream, 2 * P + PFP, c.lane, c.w);
-        load_wtile_p<NT16>(c.ring, c.wstream, 2 * P + 1 + PFP, c.lane, c.w);
+        load_wtile_p<NT16, PF>(c.ring, c.wstream, 2 * P + PF, c.lane, c.w);
+        load_wtile_p<NT16, PF>(c.ring, c.wstream, 2 * P + 1 + PF, c.lane, c.w);
     };
     constexpr int PN = (P + 1) % NPASS;   // the pass whose fragments are fetched now
     constexpr uint32_t offNA = tap_off_p<TX>((2 * PN) % 25), offNB = tap_off_p<TX>((2 * PN + 1) % 25);
     const uint8_t *pixn = c.lane_pix + (c.hi ? offNB : offNA);
-    const uint8_t *wtn = c.lane_wt + (uint32_t)((c.hi ? ((2 * PN + 1) % RINGP) : ((2 * PN) % RINGP)) * TB);
+    const uint8_t *wtn = c.lane_wt + (uint32_t)((c.hi ? ((2 * PN + 1) % PF) : ((2 * PN) % PF)) * TB);
     const v4i none[NT16 / 4] = {};
-    // everything but this pass's and the previous pass's requests has landed at the barrier (= what pass P+2's fetch needs)
-    pass_p<TX, NT16, conv_requests_p<TX, NT16>(P) + conv_requests_p<TX, NT16>(P - 1), 0, false>(acc, wf, pc, pn, pixn, wtn, false, none, dma);
+    // everything but the requests of the last FLIGHT passes has landed at the barrier (= what pass P+2's fetch needs; a plane
+    // refresh piece is requested at least 8 passes before its first read)
+    pass_p<TX, NT16, conv_in_flight_p<TX, NT16>(P, Ring<PF>::FLIGHT), 0, false, TX == 16>(acc, wc, wn, pc, pn, pixn, wtn, false, none, dma);
 }
 
-template <int TX, int NT16, int P, int NPASS>
-__device__ __forceinline__ void conv_passes_p(v4i (&acc)[Geo<TX>::NC][NT16], v4i (&wf)[NT16], v4i (&pa)[Geo<TX>::NC],
+template <int TX, int NT16, int PF, int P, int NPASS>
+__device__ __forceinline__ void conv_passes_p(v4i (&acc)[Geo<TX>::NC][NT16], v4i (&wbuf)[TX == 16 ? 2 : 1][NT16], v4i (&pa)[Geo<TX>::NC],
                                               v4i (&pb)[Geo<TX>::NC], const ConvPCtx &c, const uint32_t (&poff)[4][Geo<TX>::SLOTS])
 {
+    constexpr int NWB = TX == 16 ? 2 : 1;
     if constexpr ((P & 1) == 0)
-        conv_pass_p<TX, NT16, P, NPASS>(acc, wf, pa, pb, c, poff);
+        conv_pass_p<TX, NT16, PF, P, NPASS>(acc, wbuf[0], wbuf[NWB - 1], pa, pb, c, poff);
     else
-        conv_pass_p<TX, NT16, P, NPASS>(acc, wf, pb, pa, c, poff);
-    if constexpr (P + 1 < NPASS) conv_passes_p<TX, NT16, P + 1, NPASS>(acc, wf, pa, pb, c, poff);
+        conv_pass_p<TX, NT16, PF, P, NPASS>(acc, wbuf[NWB - 1], wbuf[0], pb, pa, c, poff);
+    if constexpr (P + 1 < NPASS) conv_passes_p<TX, NT16, PF, P + 1, NPASS>(acc, wbuf, pa, pb, c, poff);
 }
 
-template <int NQ, int NT16, int TX>
+template <int NQ, int NT16, int TX, int PF>
 __global__ __launch_bounds__(256, 2) void k_conv_p(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                    const int8_t *__restrict__ wstream, const int8_t *__restrict__ bias, int IW, int IH,
                                                    int OW, int OH, int tiles_x, int n_tiles, int n_images, int in_layout, int out_layout,
@@ -380,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_p(const uint8_t *__restrict__ i
 #pragma unroll
         for (int slot = 0; slot < SLOTS; slot++) load_piece<ALLOC>(patch, in_img, in_img_bytes, pl, slot * 4 + w, poff[pl][slot]);
 #pragma unroll
-    for (int s = 0; s < PFP; s++) load_wtile_p<NT16>(ring, wstream, s, lane, w);
+    for (int s = 0; s < PF; s++) load_wtile_p<NT16, PF>(ring, wstream, s, lane, w);
     // accumulators start at the bias: register r of tile (c, j) is channel 64 (j>>2) + 16 g + 4 (j&3) + r
     v4i acc[NC][NT16];
 #pragma unroll
@@ -397,12 +447,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_p(const uint8_t *__restrict__ i
     }
     wait_vmcnt<0>();
     block_barrier();
-    v4i wf[NT16], pa[NC], pb[NC];
+    v4i wbuf[TX == 16 ? 2 : 1][NT16], pa[NC], pb[NC];
     {   // fragments of pass 0: taps 0 / 1 of group 0, ring slots 0 / 1
         const uint8_t *p0 = ctx.lane_pix + (hi ? tap_off_p<TX>(1) : tap_off_p<TX>(0));
         const uint8_t *w0 = ctx.lane_wt + hi * TB;
 #pragma unroll
-        for (int r = 0; r < NT16; r++) wf[r] = *(const v4i *)(w0 + r * 16 * 32);
+        for (int r = 0; r < NT16; r++) wbuf[0][r] = *(const v4i *)(w0 + r * 16 * 32);
 #pragma unroll
         for (int r = 0; r < NC; r++) pa[r] = *(const v4i *)(p0 + ((r / Geo<TX>::XT) * PX + (r % Geo<TX>::XT) * 16) * 32);
     }
@@ -412,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_p(const uint8_t *__restrict__ i
 #pragma unroll
         for (int j = 0; j < NT16; j++) asm volatile("" : "+v"(acc[c][j]));
     asm volatile("s_nop 3" ::: "memory");
-    conv_passes_p<TX, NT16, 0, NPASS>(acc, wf, pa, pb, ctx, poff);
+    conv_passes_p<TX, NT16, PF, 0, NPASS>(acc, wbuf, pa, pb, ctx, poff);
     wait_vmcnt<0>();
     store_tiles_p<TX, NT16>(acc, out_img, out_img_bytes, om, OW, OH, Y0, X0, w, pos, g, false, 0, 0, act_floor);
 }
@@ -423,24 +473,28 @@ static hipError_t launch_p(const LayerGeom &g, const sicn_weights &w, const uint
                            int in_layout, int out_layout, bool relu)
 {
     constexpr int NSUB = DECONV ? NQ : 4;
+    // PF = 12 (4 passes of flight time) fits the 8 x 16 tiles of the 128-channel shapes but measured no gain on small grids
+    // (1080p: layer 6 51 vs 48 us): the weight stream's latency is not what bounds a pass there
+    constexpr int PF = 8;
+    static_assert(PF <= PAD_TILES_P, "prefetch would run off the weight stream");
     const int MW = DECONV ? g.IW : g.OW, MH = DECONV ? g.IH : g.OH;
     const int tiles_x = (MW + TX - 1) / TX, tiles_y = (MH + TILE_Y - 1) / TILE_Y;
-    constexpr size_t lds = (size_t)NSUB * Geo<TX>::ALLOC + (size_t)RINGP * WTile<NT16>::TB;
+    constexpr size_t lds = (size_t)NSUB * Geo<TX>::ALLOC + (size_t)PF * WTile<NT16>::TB;
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
     const uint32_t flags = (relu ? ACT_FLOOR_RELU : ACT_FLOOR_RAW) |
                            (nt_store_wanted((size_t)g.OH * g.OW * g.COUT * n_images) ? ACT_NT_STORE : 0u);
     const dim3 grid(xcd_grid_size(tiles_x * tiles_y * n_images));
     if constexpr (DECONV) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_deconv_p<NQ, NT16, TX>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_deconv_p<NQ, NT16, TX, PF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_deconv_p<NQ, NT16, TX>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias, g.IW, g.IH, g.OW,
+        hipLaunchKernelGGL((k_deconv_p<NQ, NT16, TX, PF>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias, g.IW, g.IH, g.OW,
                            g.OH, tiles_x, tiles_x * tiles_y, n_images, in_layout, out_layout, flags);
     } else {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_p<NQ, NT16, TX>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_p<NQ, NT16, TX, PF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_conv_p<NQ, NT16, TX>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias, g.IW, g.IH, g.OW,
+        hipLaunchKernelGGL((k_conv_p<NQ, NT16, TX, PF>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias, g.IW, g.IH, g.OW,
                            g.OH, tiles_x, tiles_x * tiles_y, n_images, in_layout, out_layout, flags);
     }
     return hipGetLastError();
