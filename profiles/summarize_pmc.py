@@ -38,6 +38,19 @@ def counters(d):
 stats = glob.glob(str(out / "stats") + "/**/*kernel_stats.csv", recursive=True)
 if stats:
     shutil.copy(stats[0], ROOT / "profiles" / f"{tag}_kernel_stats.csv")
+# the same trace per (kernel, grid size): one kernel serves several layers (layer 5 and 6 are the same deconv kernel), and the
+# bench line's roofline.avg_launch_ms is per LAYER — this is the table it has to agree with
+per = collections.defaultdict(list)
+for f in glob.glob(str(out / "stats") + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        name = short(r["Kernel_Name"])
+        grid = r.get("Grid_Size", r.get("Grid_Size_X", ""))
+        per[(name, grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+if per:
+    with open(ROOT / "profiles" / f"{tag}_per_layer_dispatch.csv", "w") as fh:
+        fh.write("kernel,grid_threads,calls,avg_ns,min_ns,max_ns\n")
+        for (name, grid), v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            fh.write(f'"{name}",{grid},{len(v)},{sum(v) / len(v):.0f},{min(v)},{max(v)}\n')
 fetch, write, sq = counters(out / "pmc_fetch"), counters(out / "pmc_write"), counters(out / "pmc_sq")
 kernels = {}
 for k in sorted(set(fetch) | set(write) | set(sq)):
@@ -75,17 +88,26 @@ try:
     dom = int(b["roofline"]["kernel"].split()[1])
     summary["dominant_layer"] = dom
     summary["dominant_kernel_algorithmic_bytes_per_launch"] = b["roofline"]["algorithmic_bytes"]
+    summary["dominant_kernel_avg_launch_ms_bench"] = b["roofline"]["avg_launch_ms"]
     summary["bench_under_rocprof"] = {k: b[k] for k in ("value", "ms_per_step", "layers", "output_bit_exact")}
     # the dominant layer's kernel: the MFMA conv/deconv kernel with the largest grid among its family
     fam = "true" if b["layers"][dom]["kernel"] == "mfma_deconv" else "false"
-    cands = [k for k in kernels if k.startswith("k_mfma16_t") and f", {fam}," in k] if b["layers"][dom]["kernel"].startswith("mfma") else \
-            [k for k in kernels if k.startswith("k_l0" if dom == 0 else "k_l7")]
+    kind = b["layers"][dom]["kernel"]
+    if kind.startswith("mfma"):
+        pre = "k_deconv_p" if kind == "mfma_deconv" else "k_conv_p"
+        cands = [k for k in kernels if k.startswith(pre)] or [k for k in kernels if k.startswith("k_mfma16_t") and f", {fam}," in k]
+    else:
+        cands = [k for k in kernels if k.startswith("k_l0" if dom == 0 else "k_l7")]
     if cands:
         best = max(cands, key=lambda k: int(k.split()[-1] or 0))
         e = kernels[best]
         summary["dominant_kernel"] = best
         if "fetch_bytes_x2_gfx950_correction" in e and "write_bytes" in e:
             summary["dominant_kernel_hbm_bytes_per_launch"] = int(e["fetch_bytes_x2_gfx950_correction"] + e["write_bytes"])
+        name, grid = best.rsplit(" ", 1)
+        if (name, grid) in per:
+            v = per[(name, grid)]
+            summary["dominant_kernel_avg_launch_ms_rocprof"] = round(sum(v) / len(v) / 1e6, 4)
 except Exception as ex:  # noqa: BLE001
     summary["_warning"] = f"bench line not parsed: {ex}"
 (ROOT / "profiles" / f"{tag}_pmc_summary.json").write_text(json.dumps(summary, indent=1) + "\n")
