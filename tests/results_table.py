@@ -48,20 +48,46 @@ def cpu_net(descs, x, form, threads, first=0, last=7):
 
 
 def with_coder(net, xg, w, h):
-    """encode (L0-L3 -> rANS-W containers) then decode (containers -> latent -> L4-L7); returns (seconds per pass,
-    bits per pixel, round trip exact).  The coder is this project's own (no reference counterpart)."""
+    """analysis -> asynchronous rANS-W encode -> decode -> synthesis, four enqueues on one stream without host
+    synchronisation; returns (seconds per pass, bits per pixel, round trip exact).  The coder is this project's own."""
+    n = xg.shape[0]
+    lat = torch.empty((n,) + net.descs[3].out_shape, dtype=torch.uint8, device="cuda")
+    back = torch.empty_like(lat)
+    rec = torch.empty((n,) + net.descs[-1].out_shape, dtype=torch.uint8, device="cuda")
+    coder = codec.LatentCoder(n, *net.descs[3].out_shape, image_width=w, image_height=h)
+
     def one():
-        lat, _ = net.run_layers(0, 3, xg)
-        slots, sizes = codec.encode_latents(lat, w, h)
-        back, _ = codec.decode_latents(slots, sizes)
-        rec, _ = net.run_layers(4, 7, back)
-        return lat, back, sizes, rec
-    lat, back, sizes, rec = one()
-    torch.cuda.synchronize()
+        net.analysis(xg, lat)
+        coder.encode(lat)
+        coder.decode(back)
+        net.synthesis(back, rec)
+    one()
+    coder.check()
     t = gpu_time(one, reps=10)
+    coder.check()
     ref, _ = net.forward(xg)
     torch.cuda.synchronize()
-    return t, 8.0 * sum(sizes) / (xg.shape[0] * w * h), bool(torch.equal(back, lat) and torch.equal(rec, ref))
+    return t, 8.0 * sum(coder.sizes()) / (n * w * h), bool(torch.equal(back, lat) and torch.equal(rec, ref))
+
+
+def hyperprior(xg, w, h):
+    """BASELINE configs[4]: GDN main transform + hyper stacks + mode-3 / mode-4 coders, encode + decode."""
+    from simple_image_compression_network_amd.hyperprior import HyperpriorCodec
+    n = xg.shape[0]
+    hc = HyperpriorCodec(w, h, n, seed=0)
+    out = torch.empty((n,) + hc.main.descs[-1].out_shape, dtype=torch.uint8, device="cuda")
+
+    def one():
+        hc.encode(xg)
+        hc.decode(out)
+    one()
+    hc.check()
+    t = gpu_time(one, reps=5)
+    hc.check()
+    direct = torch.empty_like(out)
+    hc.main.forward(xg, direct, want_latent=False)
+    torch.cuda.synchronize()
+    return t, 8.0 * sum(hc.bytes_per_image()) / (n * w * h), bool(torch.equal(hc.y_hat, hc.y) and torch.equal(out, direct))
 
 
 def fracs(descs, first, last, n_img, secs):
@@ -134,6 +160,11 @@ try:
     cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
 except Exception:
     pass
+t_h, bpp_h, rt_h = hyperprior(xg, 3840, 2160)
+rows.append({"config": "5: hyperprior configuration (GDN / IGDN, hyper stacks, conditional coder), 8 x 3840x2160 on ONE GPU",
+             "pixels": 8 * 3840 * 2160, "gpu1_Mpx_s": 8 * 3840 * 2160 / t_h / 1e6, "coded_bits_per_pixel": bpp_h,
+             "coder_round_trip_exact": rt_h, "note": "no reference counterpart: parity unpinned; checked stage by stage against "
+             "this project's oracle in tests/test_hyperprior.py"})
 print(json.dumps({"host": {"cpu": cpu, "threads_used": NTHR, "nproc": os.cpu_count(), "platform": platform.platform(),
                            "oracle_flags": "gcc -O3 -fopenmp, AVX2 clone of the dot product"},
                   "gpu": torch.cuda.get_device_name(0), "rows": rows}, indent=1))
