@@ -122,7 +122,10 @@ def main():
     dev = torch.device("cuda", local_rank % max(ndev, 1))
     torch.cuda.set_device(dev)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where the bookkeeping collectives live
-    if world > 1:
+    # SICN_BENCH_FORCE_DIST=1: create the process group (and run every bookkeeping collective) even for one rank, so that the
+    # RCCL code path of the N > 1 runs can be exercised on a 1-GPU box (launch under torch.distributed.run --nproc-per-node 1)
+    use_dist = world > 1 or os.environ.get("SICN_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
         else:
@@ -134,7 +137,7 @@ def main():
     x = torch.from_numpy(host).to(dev)
     # weights: rank 0's PARAM tables, replicated with one broadcast (no-op on one GPU)
     params = api.load_param_weights()
-    if world > 1:
+    if use_dist:
         from simple_image_compression_network_amd.dist import broadcast_params
         if rank != 0:
             for pair in params:
@@ -151,18 +154,18 @@ def main():
 
     def timed(fn, steps):
         """barrier + synchronize on both sides, MAX over ranks."""
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -190,7 +193,7 @@ def main():
     # bookkeeping collectives only: verdict + one checksum per rank, so rank 0 can show every shard ran
     mine = torch.tensor([verdict, zlib.adler32(out_h.reshape(-1)) & 0xFFFFFFFF], dtype=torch.int64, device=cdev)
     gathered = [mine]
-    if world > 1:
+    if use_dist:
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
     verdicts = [int(g[0].item()) for g in gathered]
@@ -249,7 +252,7 @@ def main():
                          "hyper / GDN parameters"}
         del hc, out_h2, direct
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -315,8 +318,10 @@ def main():
         res["hyperprior"] = hyper
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(host[0], args.cpu_sample, lat_h[0], out_h[0])
+    if use_dist:
+        res["config"]["collectives"] = f"torch.distributed backend {dist.get_backend()} (bookkeeping only: weight broadcast, barrier, MAX of the timed region, checksum all-gather)"
     print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

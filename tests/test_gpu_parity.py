@@ -476,6 +476,24 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     assert d["with_coder"]["round_trip_exact"] is True and d["with_coder"]["value"] > 0
 
 
+def test_bench_rccl_code_path_single_rank():
+    """The driver runs bench.py with nccl (= RCCL) on N GPUs; a 1-GPU box can at least execute that whole code path — process
+    group on the GPU, weight broadcast, barrier, MAX all-reduce of the timed region, checksum all-gather — with one rank
+    (SICN_BENCH_FORCE_DIST=1)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--no-hyperprior", "--width", "512", "--height", "256", "--images-per-gpu", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT), env=dict(os.environ, SICN_BENCH_FORCE_DIST="1"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "nccl" in d["config"]["collectives"] and d["value"] > 0 and d["with_coder"]["round_trip_exact"] is True
+
+
 def test_committed_small_vectors_on_gpu(api):
     """The HIP path against the committed fixture tests/golden/small_vectors.npz (no oracle call at all)."""
     from test_oracle_golden import _small_vectors
