@@ -21,39 +21,40 @@
 
 namespace sicn {
 
-// r = max{ r : r^2 n <= 2^32 } = floor(2^16 / sqrt(n)), 1 <= n < 2^30.  Float estimate (within +-1: relative error
-// of cvt + v_rsq_f32 < 2^-21, r <= 46341 for n >= 2) and an exact integer fix-up.
+// r = max{ r : r^2 n <= 2^32 } = floor(2^16 / sqrt(n)), 1 <= n < 2^30.  Float estimate r0 (cvt + v_rsq_f32 are good to < 2^-21
+// relative, r <= 46341 for n >= 2: |r0 - r| <= 1) and a BRANCH-FREE exact fix-up: ok(q) = [q^2 n <= 2^32] is monotone, so
+// r = r0 - 1 + ok(r0) + ok(r0 + 1).  (Round 2's first version looped on ok(): the data-dependent branches cost more than the
+// arithmetic — 387 s_cbranch in the kernel.)
 __device__ __forceinline__ uint32_t gdn_rsqrt16(uint32_t n)
 {
-    if (n <= 1) return 65536u;
-    uint32_t r = (uint32_t)(65536.0f * __frsqrt_rn((float)n));
-    r = min(r, 65535u);
-    auto ok = [&](uint32_t q) {   // q^2 n <= 2^32, q <= 65535 (q^2 fits 32 bits)
+    uint32_t r0 = (uint32_t)(65536.0f * __frsqrt_rn((float)n));
+    r0 = max(1u, min(r0, 65534u));
+    auto ok = [&](uint32_t q) -> uint32_t {   // q <= 65535: q^2 fits 32 bits
         const uint32_t q2 = q * q, lo = q2 * n, hi = __umulhi(q2, n);
-        return hi == 0 || (hi == 1 && lo == 0);
+        return (hi == 0 || (hi == 1 && lo == 0)) ? 1u : 0u;
     };
-    while (!ok(r)) r--;
-    while (r < 65535u && ok(r + 1)) r++;
-    return r;
+    const uint32_t r = r0 - 1 + ok(r0) + ok(r0 + 1);
+    return n <= 1 ? 65536u : r;
 }
 
-// r = max{ r : r^2 <= n 2^16 } = floor(2^8 sqrt(n)), n < 2^30 (r < 2^23).
+// r = max{ r : r^2 <= n 2^16 } = floor(2^8 sqrt(n)), n < 2^30 (r < 2^23): the float estimate is within 2 (relative 2^-21 of up to
+// 5.9e6), so r = r0 - 2 + ok(r0 - 1) + ok(r0) + ok(r0 + 1) + ok(r0 + 2) with ok(q) = [q^2 <= n 2^16] (64-bit compare).
 __device__ __forceinline__ uint32_t gdn_sqrt8(uint32_t n)
 {
     const uint32_t nlo = n << 16, nhi = n >> 16;
-    uint32_t r = (uint32_t)(256.0f * __fsqrt_rn((float)n));
-    auto ok = [&](uint32_t q) {
+    uint32_t r0 = (uint32_t)(256.0f * __fsqrt_rn((float)n));
+    r0 = max(r0, 2u);
+    auto ok = [&](uint32_t q) -> uint32_t {
         const uint32_t lo = q * q, hi = __umulhi(q, q);
-        return hi < nhi || (hi == nhi && lo <= nlo);
+        return (hi < nhi || (hi == nhi && lo <= nlo)) ? 1u : 0u;
     };
-    while (!ok(r)) r--;
-    while (ok(r + 1)) r++;
-    return r;
+    return r0 - 2 + ok(r0 - 1) + ok(r0) + ok(r0 + 1) + ok(r0 + 2);
 }
 
-__device__ __forceinline__ int gdn_out(int x, uint32_t n, int inverse, int sh)
+template <bool INVERSE>
+__device__ __forceinline__ int gdn_out(int x, uint32_t n, int sh)
 {
-    const uint32_t r = inverse ? gdn_sqrt8(n) : gdn_rsqrt16(n);
+    const uint32_t r = INVERSE ? gdn_sqrt8(n) : gdn_rsqrt16(n);
     int t = (x * (int)r + (1 << (sh - 1))) >> sh;   // |x r| < 2^30; arithmetic shift
     return max(-128, min(127, t));
 }
@@ -62,10 +63,10 @@ struct GdnMap {   // byte offset of 16-byte chunk k of position p: (p / P) * pla
     uint32_t P, plane, pix, grp;
 };
 
-template <int NJ>
+template <int NJ, bool INVERSE>
 __global__ __launch_bounds__(256, 2) void k_gdn(uint8_t *__restrict__ data, const int8_t *__restrict__ gamma_img,
                                                 const uint32_t *__restrict__ beta, long long image_bytes, uint32_t n_pos,
-                                                GdnMap map, int inverse, int sh, int blocks_per_image)
+                                                GdnMap map, int sh, int blocks_per_image)
 {
     constexpr int C = 64 * NJ, NT = C / 16;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void k_gdn(uint8_t *__restrict__ data, cons
                     for (int r = 0; r < 4; r++) {
                         int x = (int)(int8_t)((uint32_t)xf[J][d] >> (8 * r));
                         x = max(x, -127);
-                        const int t = gdn_out(x, (uint32_t)acc[4 * J + d][r], inverse, sh);
+                        const int t = gdn_out<INVERSE>(x, (uint32_t)acc[4 * J + d][r], sh);
                         packed |= ((uint32_t)t & 255u) << (8 * r);
                     }
                     y[d] = (int)packed;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void k_gdn_generic(uint8_t *__restrict__ data,
             const int t = max((int)v[j], -127);
             n += (uint32_t)(uint8_t)gamma[(size_t)i * C + j] * (uint32_t)(t * t);
         }
-        data[p0 * C + e] = (uint8_t)(gdn_out(max((int)v[i], -127), n, inverse, sh) & 255);
+        data[p0 * C + e] = (uint8_t)((inverse ? gdn_out<true>(max((int)v[i], -127), n, sh) : gdn_out<false>(max((int)v[i], -127), n, sh)) & 255);
     }
 }
 
@@ -210,18 +211,15 @@ hipError_t launch_gdn(const sicn_gdn &g, uint8_t *data, int layout, int W, int H
     const int blocks = (int)((hw + 255) / 256);
     const int gx = blocks < 2048 ? blocks : 2048;   // a workgroup re-uses its gamma image over several blocks
     const size_t lds = (size_t)C * C + (size_t)C * 4;
-    if (C == 128) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_gdn<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto go = [&](auto kernel) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_gdn<2>, dim3((unsigned)gx, (unsigned)n_images), dim3(256), lds, stream, data, g.d_gamma_mfma, g.d_beta,
-                           image_bytes, (uint32_t)hw, m, g.inverse, g.shift, blocks);
-    } else {
-        hipError_t e = hipFuncSetAttribute((const void *)k_gdn<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_gdn<3>, dim3((unsigned)gx, (unsigned)n_images), dim3(256), lds, stream, data, g.d_gamma_mfma, g.d_beta,
-                           image_bytes, (uint32_t)hw, m, g.inverse, g.shift, blocks);
-    }
-    return hipGetLastError();
+        hipLaunchKernelGGL(kernel, dim3((unsigned)gx, (unsigned)n_images), dim3(256), lds, stream, data, g.d_gamma_mfma, g.d_beta,
+                           image_bytes, (uint32_t)hw, m, g.shift, blocks);
+        return hipGetLastError();
+    };
+    if (C == 128) return g.inverse ? go(k_gdn<2, true>) : go(k_gdn<2, false>);
+    return g.inverse ? go(k_gdn<3, true>) : go(k_gdn<3, false>);
 }
 
 hipError_t launch_gdn_generic(const sicn_gdn &g, uint8_t *data, long long n_pos, hipStream_t stream)

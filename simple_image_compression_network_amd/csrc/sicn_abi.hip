@@ -574,8 +574,8 @@ extern "C" int sicn_gdn_apply(const sicn_gdn *g, uint8_t *lanes, long long n_pos
 {
     if (!g || n_positions < 0 || (n_positions && !lanes)) return SICN_EINVAL;
     hipStream_t stream = (hipStream_t)hip_stream;
-    // chunks of at most 2^23 positions (x 192 B < 2 GiB: the kernel addresses a chunk through one buffer descriptor)
-    const long long chunk = 1LL << 23;
+    // chunks of < 2 GiB (the kernel addresses a chunk through one buffer descriptor with 31-bit offsets)
+    const long long chunk = ((1LL << 31) - 4096) / g->channels;
     for (long long p = 0; p < n_positions; p += chunk) {
         const long long n = n_positions - p < chunk ? n_positions - p : chunk;
         hipError_t e = launch_gdn(*g, lanes + (size_t)p * g->channels, 0 /* NHWC */, (int)n, 1, 1, stream);
