@@ -180,6 +180,24 @@ __device__ __forceinline__ void ransw_build(RanswTab &t, const uint16_t *freq, i
     t.rcp[2 * lane + 1] = ransw_rcp(f1);
 }
 
+// The 16-bit words of a stream pass through a small LDS RING (8 KB) instead of a buffer sized for the worst case (33 KB):
+// the worst case still fits the stream's scratch slot in global memory, but a wave now costs 9 KB (mode 3) / 24 KB (mode 4) of
+// LDS, so a CU holds all of its streams at once (a 4K latent gives a CU about 12) instead of 4 at a time — the coders are
+// latency-bound serial chains, occupancy is their only source of throughput.
+//   encoder: words are produced at DEcreasing global word indices gpos-1, gpos-2, ..; ring slot = index % RING_WORDS; whenever
+//            fewer than one step's worth (64) of slots is left, the words [gpos, top) go out to the scratch slot.
+//   decoder: words are consumed at INcreasing indices; before every block of 4 steps (<= 256 words) the ring is topped up.
+constexpr uint32_t RING_WORDS = 4096;
+__device__ __forceinline__ void ring_flush(const uint16_t *ring, uint16_t *dst, uint32_t gpos, uint32_t top, uint32_t lane)
+{
+    for (uint32_t i = gpos + lane; i < top; i += 64) dst[i] = ring[i & (RING_WORDS - 1)];
+}
+__device__ __forceinline__ uint32_t ring_fill(uint16_t *ring, const uint16_t *src, uint32_t loaded, uint32_t upto, uint32_t lane)
+{
+    for (uint32_t i = loaded + lane; i < upto; i += 64) ring[i & (RING_WORDS - 1)] = src[i];
+    return upto;
+}
+
 __global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__ lat_, uint32_t n, uint32_t ns,
                                                      const uint16_t *__restrict__ freq_g_, uint8_t *__restrict__ scratch_,
                                                      uint32_t *__restrict__ lens_, size_t s_lat, size_t s_ws)
@@ -189,13 +207,14 @@ __global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__
     uint8_t *scratch = img_ptr(scratch_, s_ws);
     uint32_t *lens = img_ptr(lens_, s_ws);
     __shared__ RanswTab tab;
-    __shared__ __attribute__((aligned(16))) uint16_t words[WCAP / 2];
+    __shared__ __attribute__((aligned(16))) uint16_t words[RING_WORDS];
     const uint32_t st = blockIdx.x, lane = threadIdx.x;
     ransw_build(tab, freq_g, (int)lane);
     __syncthreads();
     const uint32_t begin = st * WSS, cnt = min(WSS, n - begin), blocks = (cnt + 255) / 256;
     const bool aligned = (reinterpret_cast<uintptr_t>(lat) & 3) == 0;   // begin is a multiple of 16384
-    uint32_t pos = WCAP / 2;        // word index, the same in every lane
+    uint16_t *dst = (uint16_t *)(scratch + (size_t)st * WCAP);
+    uint32_t pos = WCAP / 2, top = WCAP / 2;   // word indices inside the scratch slot, the same in every lane: [pos, top) is in the ring
     uint32_t x = RANSW_L;
     const unsigned long long below = (1ull << lane) - 1;
     auto load4 = [&](uint32_t q) -> uint32_t {   // the lane's 4 symbols of block q (missing ones read as 0)
@@ -223,7 +242,7 @@ __global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__
             const unsigned long long mask = __ballot(emit);
             pos -= (uint32_t)__popcll(mask);
             if (emit) {
-                words[pos + (uint32_t)__popcll(mask & below)] = (uint16_t)x;   // ascending lane order inside the step
+                words[(pos + (uint32_t)__popcll(mask & below)) & (RING_WORDS - 1)] = (uint16_t)x;   // ascending lane order inside the step
                 x >>= 16;
             }
             if (active) {
@@ -232,14 +251,18 @@ __global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__
                 x = (qq << PROB_BITS) + r + c;
             }
         }
+        if (top - pos > RING_WORDS - 4 * 64 - 128) {   // the next 4 steps (and the final states) must still fit
+            __syncthreads();
+            ring_flush(words, dst, pos, top, lane);
+            __syncthreads();
+            top = pos;
+        }
     }
     pos -= 128;   // the 64 final states, lane 0 first (the word index may be odd: two halves)
-    words[pos + 2 * lane] = (uint16_t)x;
-    words[pos + 2 * lane + 1] = (uint16_t)(x >> 16);
+    words[(pos + 2 * lane) & (RING_WORDS - 1)] = (uint16_t)x;
+    words[(pos + 2 * lane + 1) & (RING_WORDS - 1)] = (uint16_t)(x >> 16);
     __syncthreads();
-    // LDS -> the tail of this stream's scratch slot, coalesced
-    uint16_t *dst = (uint16_t *)(scratch + (size_t)st * WCAP);
-    for (uint32_t i = pos + lane; i < WCAP / 2; i += 64) dst[i] = words[i];
+    ring_flush(words, dst, pos, top, lane);
     if (lane == 0) lens[st] = (WCAP / 2 - pos) * 2;
 }
 
@@ -261,7 +284,7 @@ __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__
     __shared__ RanswTab tab;
     __shared__ uint16_t freq[128];
     __shared__ uint8_t slot[4096];
-    __shared__ __attribute__((aligned(16))) uint16_t words[WCAP / 2];
+    __shared__ __attribute__((aligned(16))) uint16_t words[RING_WORDS];
     const uint32_t st = blockIdx.x, lane = threadIdx.x;
     freq[2 * lane] = (uint16_t)(freq_bytes[4 * lane] | (freq_bytes[4 * lane + 1] << 8));
     freq[2 * lane + 1] = (uint16_t)(freq_bytes[4 * lane + 2] | (freq_bytes[4 * lane + 3] << 8));
@@ -281,7 +304,7 @@ __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__
     }
     const uint32_t nwords = len / 2;
     const uint16_t *src = (const uint16_t *)(payload + off);
-    for (uint32_t i = lane; i < nwords; i += 64) words[i] = src[i];
+    uint32_t loaded = ring_fill(words, src, 0, min(nwords, RING_WORDS), lane);
     __syncthreads();
     uint32_t x = words[2 * lane] | ((uint32_t)words[2 * lane + 1] << 16);
     uint32_t wpos = 128;
@@ -289,6 +312,11 @@ __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__
     const bool aligned = (reinterpret_cast<uintptr_t>(lat) & 3) == 0;
     bool bad = false;
     for (uint32_t q = 0; q < blocks; q++) {
+        if (loaded < nwords && loaded - min(wpos, loaded) < 4 * 64) {   // top the ring up: the 4 steps below read <= 256 words
+            __syncthreads();
+            loaded = ring_fill(words, src, loaded, min(nwords, wpos + RING_WORDS), lane);
+            __syncthreads();
+        }
         uint32_t out4 = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -302,8 +330,8 @@ __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__
             const unsigned long long mask = __ballot(need);
             if (need) {
                 const uint32_t idx = wpos + (uint32_t)__popcll(mask & below);
-                if (idx < nwords)
-                    x = (x << 16) | words[idx];
+                if (idx < loaded)        // loaded <= nwords; a stream that runs dry is malformed
+                    x = (x << 16) | words[idx & (RING_WORDS - 1)];
                 else
                     bad = true;
             }
