@@ -92,8 +92,9 @@ typedef struct sicn_options {
     int32_t tile_x;          /* 0: by layer shape and grid size; 16 / 32: force that M-tile width   */
     int32_t strip_chunks;    /* 0: automatic; n: cut the vertical strips of the RGB layers into n   */
     int32_t no_phase_layout; /* 0: default; 1: never use the PHASE layout; 2: not towards layer 7   */
-    int32_t split_n;         /* 0: automatic; 1: never split; 2, 3, 4: output-channel split of the  */
-                             /*    MFMA layers (grids smaller than the chip)                        */
+    int32_t split_n;         /* 0: automatic (grids of at most 128 tiles: half the CUs idle); 1: never; > 1: always — the */
+                             /*    pipelined 8 x 16 kernels give each workgroup 64 of the layer's 128 / 192 output     */
+                             /*    channels (k_mfma16p.hip, launch_p)                                                 */
     int32_t wave_tile;       /* 0: automatic; 64: always the 64 x 128-per-wave kernels (two waves per SIMD); 128: the  */
                              /*    128 x 128-per-wave kernel (one wave per SIMD) wherever it exists               */
     int32_t prefetch;        /* 0: automatic; 1: never, 2: wherever it exists — the software-pipelined kernels         */

@@ -406,8 +406,13 @@ static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint
     {
         const int tx = narrow ? 16 : 32;
         const bool wide_asked = !DECONV && NQ == 4 && NT16 == 8 && !narrow && o.wave_tile == 128;
-        if (o.prefetch != 1 && !wide_asked && pipelined_supported(g, tx))
-            return launch_pipelined(g, w, in, out, n_images, stream, in_layout, out_layout, relu, tx);
+        if (o.prefetch != 1 && !wide_asked && pipelined_supported(g, tx)) {
+            // grids that leave half of the CUs without a workgroup: split the output channels over 2 / 3 workgroups
+            // (measured, r02: at 192 - 255 tiles the split is a wash or a loss; at <= 72 it takes 20 - 35 % off the layer)
+            const long tiles16 = (long)((MW + 15) / 16) * ((MH + TILE_Y - 1) / TILE_Y) * n_images;
+            const bool split = tx == 16 && (o.split_n > 1 || (o.split_n == 0 && tiles16 <= 128));
+            return launch_pipelined(g, w, in, out, n_images, stream, in_layout, out_layout, relu, tx, split);
+        }
     }
     // layers 1 / 2 (conv 128 -> 128): the wide form (one wave per SIMD, 128 x 128 tile per wave, k_mfma16w.hip) is bit-exact but
     // measured 8 % SLOWER than this file's kernels on 8 x 4K (its per-tile prologue / epilogue has no partner wave to hide

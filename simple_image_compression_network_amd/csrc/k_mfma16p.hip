@@ -45,16 +45,18 @@ struct WTile {
     static constexpr int WR = (NPB + 3) / 4;         // LDS-DMA instructions per wave and tile: 1 / 2
 };
 
-template <int NT16, int PF>
+// NTF = weight tiles (of 16 channels) of the whole layer: the stride of the stream; NT16 <= NTF = the ones this workgroup
+// computes (output-channel split, see launch_p); `wstream` already points at its first row
+template <int NT16, int NTF, int PF>
 __device__ __forceinline__ void load_wtile_p(uint8_t *ring, const int8_t *wstream, int tile, int lane, int w)
 {
     constexpr int TB = WTile<NT16>::TB, NPB = WTile<NT16>::NPB, WR = WTile<NT16>::WR;
-    const int8_t *src = wstream + (size_t)tile * TB + lane * 16;
+    const int8_t *src = wstream + (size_t)tile * WTile<NTF>::TB + lane * 16;
     uint8_t *dst = ring + (tile % PF) * TB;
 #pragma unroll
     for (int r = 0; r < WR; r++) {
         int piece = r * 4 + w;
-        if (piece >= NPB) piece -= 2;   // NPB == 6: waves 2, 3 re-load pieces 4, 5 (same bytes): every wave issues WR requests
+        if (piece >= NPB) piece -= 2;   // NPB == 6 / 2: waves 2, 3 re-load pieces 4, 5 / 0, 1 (same bytes): every wave issues WR requests
         __builtin_amdgcn_global_load_lds(GLB_PTR(src + piece * 1024), LDS_PTR(dst + piece * 1024), 16, 0, 0);
     }
 }
@@ -133,9 +135,9 @@ __device__ __forceinline__ void pass_p(v4i (&acc)[Geo<TX>::NC][NT16], const v4i 
 template <int TX, int NT16>
 __device__ __forceinline__ void store_tiles_p(v4i (&acc)[Geo<TX>::NC][NT16], uint8_t *out_img, int out_img_bytes, const TensorMap &om,
                                               int MW, int MH, int Y0, int X0, int w, int pos, int g, bool deconv, int py, int px,
-                                              uint32_t act_floor)
+                                              uint32_t act_floor, uint32_t cg0)
 {
-    constexpr int NC = Geo<TX>::NC, XT = Geo<TX>::XT;
+    constexpr int NC = Geo<TX>::NC, XT = Geo<TX>::XT;   // cg0: first 32-channel group of this workgroup's output channels
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the last MFMAs' results -> VALU
 #pragma unroll
     for (int c = 0; c < NC; c++)
@@ -147,7 +149,7 @@ __device__ __forceinline__ void store_tiles_p(v4i (&acc)[Geo<TX>::NC][NT16], uin
         const int gy = Y0 + 2 * w + c / XT, gx = X0 + (c % XT) * 16 + pos;
         const bool ok = gy < MH && gx < MW;
         const int oy_ = deconv ? 2 * gy + py : gy, ox_ = deconv ? 2 * gx + px : gx;
-        const uint32_t off0 = tensor_offset(om, oy_, ox_, (uint32_t)(g >> 1)) + 16u * (g & 1);
+        const uint32_t off0 = tensor_offset(om, oy_, ox_, (uint32_t)(g >> 1) + cg0) + 16u * (g & 1);
 #pragma unroll
         for (int J = 0; J < NT16 / 4; J++) {
             v4i v;
@@ -180,20 +182,23 @@ __device__ __forceinline__ TileCoord tile_coord(int tiles_x, int n_tiles, int n_
 // =====================================================================================================================
 // deconv522<>: NQ / 2 passes per tap (channel pairs q, q+1 of one tap), the tap loop stays a loop
 // =====================================================================================================================
-template <int NQ, int NT16, int TX, int PF>
+template <int NQ, int NT16, int NTF, int TX, int PF>
 __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                      const int8_t *__restrict__ wstream, const int8_t *__restrict__ bias, int IW, int IH,
                                                      int OW, int OH, int tiles_x, int n_tiles, int n_images, int in_layout,
                                                      int out_layout, uint32_t act_floor)
 {
-    constexpr int CIN = NQ * 32, COUT = NT16 * 16, NC = Geo<TX>::NC, PPT = NQ / 2;   // passes per tap
+    constexpr int CIN = NQ * 32, COUT = NTF * 16, COUTW = NT16 * 16, NC = Geo<TX>::NC, PPT = NQ / 2;   // passes per tap
     constexpr int PX = Geo<TX>::PX, ALLOC = Geo<TX>::ALLOC, SLOTS = Geo<TX>::SLOTS;
     constexpr int TB = WTile<NT16>::TB, WR = WTile<NT16>::WR;
+    const int split = blockIdx.y;                    // this workgroup's COUTW output channels start at split * COUTW
+    wstream += split * TB;
+    bias += split * COUTW;
     constexpr int NSTORE = NC * NT16 / 4;            // output stores per wave and phase
     constexpr int FL = Ring<PF>::FLIGHT;
     constexpr int VM = FL * 2 * WR;                  // requests of the last FL passes
     constexpr int BIAS_LDS = (Geo<TX>::PIX * KSTEP + 1023) / 1024 * 1024;   // the padding pieces behind sub-patch 0's positions
-    static_assert(BIAS_LDS + COUT <= ALLOC, "no room for the bias behind the patch");
+    static_assert(BIAS_LDS + COUTW <= ALLOC, "no room for the bias behind the patch");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *patch = smem, *ring = smem + NQ * ALLOC;
 
@@ -221,14 +226,14 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
             load_piece<ALLOC>(patch, in_img, in_img_bytes, sub, slot * 4 + w, ps.ok ? ps.off + (uint32_t)sub * im.grp : OOB);
     }
 #pragma unroll
-    for (int s = 0; s < PF; s++) load_wtile_p<NT16, PF>(ring, wstream, s, lane, w);
+    for (int s = 0; s < PF; s++) load_wtile_p<NT16, NTF, PF>(ring, wstream, s, lane, w);
     // the bias goes to LDS (padding behind sub-patch 0): reading it from global memory at the start of every phase would make
     // hipcc drain vmcnt there, i.e. wait for the previous phase's stores
     uint32_t bias_dw = 0;
-    if (tid < COUT / 4) bias_dw = ((const uint32_t *)bias)[tid];
+    if (tid < COUTW / 4) bias_dw = ((const uint32_t *)bias)[tid];
     wait_vmcnt<0>();
     block_barrier();   // every wave's DMA has landed — including the padding piece (zeros) the bias is about to replace
-    if (tid < COUT / 4) ((uint32_t *)(patch + BIAS_LDS))[tid] = bias_dw;
+    if (tid < COUTW / 4) ((uint32_t *)(patch + BIAS_LDS))[tid] = bias_dw;
     block_barrier();
 
     // a pass covers steps (s0, s0 + 1) = channel groups (q, q + 1) of one tap: fragments at
@@ -256,8 +261,8 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
             const uint8_t *pixn = lane_pix + (last ? toff_next : toff + (uint32_t)((q + 2) * ALLOC));
             const uint8_t *wtn = lane_wt + (uint32_t)(((s0 + 2 + hi) % PF) * TB);
             auto dma = [&]() {
-                load_wtile_p<NT16, PF>(ring, wstream, s0 + PF, lane, w);
-                load_wtile_p<NT16, PF>(ring, wstream, s0 + 1 + PF, lane, w);
+                load_wtile_p<NT16, NTF, PF>(ring, wstream, s0 + PF, lane, w);
+                load_wtile_p<NT16, NTF, PF>(ring, wstream, s0 + 1 + PF, lane, w);
             };
             // the previous phase's NSTORE stores are younger than the tiles awaited in the first FL passes of a phase: they
             // are counted, not waited for
@@ -306,7 +311,8 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
             }
         }
         if (ph == 3) wait_vmcnt<0>();  // the padded tail of the weight prefetch must land before exit
-        store_tiles_p<TX, NT16>(acc, out_img, out_img_bytes, om, IW, IH, Y0, X0, w, pos, g, true, py, px, act_floor);
+        store_tiles_p<TX, NT16>(acc, out_img, out_img_bytes, om, IW, IH, Y0, X0, w, pos, g, true, py, px, act_floor,
+                                (uint32_t)(split * (COUTW / 32)));
     }
 }
 
@@ -352,7 +358,7 @@ struct ConvPCtx {
     int lane, w, hi;
 };
 
-template <int TX, int NT16, int PF, int P, int NPASS>
+template <int TX, int NT16, int NTF, int PF, int P, int NPASS>
 __device__ __forceinline__ void conv_pass_p(v4i (&acc)[Geo<TX>::NC][NT16], const v4i (&wc)[NT16], v4i (&wn)[NT16],
                                             const v4i (&pc)[Geo<TX>::NC], v4i (&pn)[Geo<TX>::NC], const ConvPCtx &c,
                                             const uint32_t (&poff)[4][Geo<TX>::SLOTS])
@@ -367,8 +373,8 @@ __device__ __forceinline__ void conv_pass_p(v4i (&acc)[Geo<TX>::NC][NT16], const
         if constexpr (rpB >= 0)
             load_piece<ALLOC>(c.patch, c.in_img, c.in_img_bytes, rpB, refresh_slot_p(tB, S) * 4 + c.w,
                               poff[rpB][refresh_slot_p(tB, S)] + (uint32_t)((rpB == 3) ? qB : qB + 1) * c.qstride);
-        load_wtile_p<NT16, PF>(c.ring, c.wstream, 2 * P + PF, c.lane, c.w);
-        load_wtile_p<NT16, PF>(c.ring, c.wstream, 2 * P + 1 + PF, c.lane, c.w);
+        load_wtile_p<NT16, NTF, PF>(c.ring, c.wstream, 2 * P + PF, c.lane, c.w);
+        load_wtile_p<NT16, NTF, PF>(c.ring, c.wstream, 2 * P + 1 + PF, c.lane, c.w);
     };
     constexpr int PN = (P + 1) % NPASS;   // the pass whose fragments are fetched now
     constexpr uint32_t offNA = tap_off_p<TX>((2 * PN) % 25), offNB = tap_off_p<TX>((2 * PN + 1) % 25);
@@ -380,27 +386,30 @@ __device__ __forceinline__ void conv_pass_p(v4i (&acc)[Geo<TX>::NC][NT16], const
     pass_p<TX, NT16, conv_in_flight_p<TX, NT16>(P, Ring<PF>::FLIGHT), 0, false, TX == 16>(acc, wc, wn, pc, pn, pixn, wtn, false, none, dma);
 }
 
-template <int TX, int NT16, int PF, int P, int NPASS>
+template <int TX, int NT16, int NTF, int PF, int P, int NPASS>
 __device__ __forceinline__ void conv_passes_p(v4i (&acc)[Geo<TX>::NC][NT16], v4i (&wbuf)[TX == 16 ? 2 : 1][NT16], v4i (&pa)[Geo<TX>::NC],
                                               v4i (&pb)[Geo<TX>::NC], const ConvPCtx &c, const uint32_t (&poff)[4][Geo<TX>::SLOTS])
 {
     constexpr int NWB = TX == 16 ? 2 : 1;
     if constexpr ((P & 1) == 0)
-        conv_pass_p<TX, NT16, PF, P, NPASS>(acc, wbuf[0], wbuf[NWB - 1], pa, pb, c, poff);
+        conv_pass_p<TX, NT16, NTF, PF, P, NPASS>(acc, wbuf[0], wbuf[NWB - 1], pa, pb, c, poff);
     else
-        conv_pass_p<TX, NT16, PF, P, NPASS>(acc, wbuf[NWB - 1], wbuf[0], pb, pa, c, poff);
-    if constexpr (P + 1 < NPASS) conv_passes_p<TX, NT16, PF, P + 1, NPASS>(acc, wbuf, pa, pb, c, poff);
+        conv_pass_p<TX, NT16, NTF, PF, P, NPASS>(acc, wbuf[NWB - 1], wbuf[0], pb, pa, c, poff);
+    if constexpr (P + 1 < NPASS) conv_passes_p<TX, NT16, NTF, PF, P + 1, NPASS>(acc, wbuf, pa, pb, c, poff);
 }
 
-template <int NQ, int NT16, int TX, int PF>
+template <int NQ, int NT16, int NTF, int TX, int PF>
 __global__ __launch_bounds__(256, 2) void k_conv_p(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                    const int8_t *__restrict__ wstream, const int8_t *__restrict__ bias, int IW, int IH,
                                                    int OW, int OH, int tiles_x, int n_tiles, int n_images, int in_layout, int out_layout,
                                                    uint32_t act_floor)
 {
-    constexpr int CIN = NQ * 32, COUT = NT16 * 16, NC = Geo<TX>::NC, NPASS = 25 * NQ / 2;
+    constexpr int CIN = NQ * 32, COUT = NTF * 16, COUTW = NT16 * 16, NC = Geo<TX>::NC, NPASS = 25 * NQ / 2;
     static_assert(NQ % 2 == 0, "channel groups are consumed in pairs");
     constexpr int PX = Geo<TX>::PX, ALLOC = Geo<TX>::ALLOC, SLOTS = Geo<TX>::SLOTS, TB = WTile<NT16>::TB;
+    const int split = blockIdx.y;                    // this workgroup's COUTW output channels start at split * COUTW
+    wstream += split * TB;
+    bias += split * COUTW;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *patch = smem, *ring = smem + 4 * ALLOC;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_p(const uint8_t *__restrict__ i
 #pragma unroll
         for (int slot = 0; slot < SLOTS; slot++) load_piece<ALLOC>(patch, in_img, in_img_bytes, pl, slot * 4 + w, poff[pl][slot]);
 #pragma unroll
-    for (int s = 0; s < PF; s++) load_wtile_p<NT16, PF>(ring, wstream, s, lane, w);
+    for (int s = 0; s < PF; s++) load_wtile_p<NT16, NTF, PF>(ring, wstream, s, lane, w);
     // accumulators start at the bias: register r of tile (c, j) is channel 64 (j>>2) + 16 g + 4 (j&3) + r
     v4i acc[NC][NT16];
 #pragma unroll
@@ -462,13 +471,17 @@ __global__ __launch_bounds__(256, 2) void k_conv_p(const uint8_t *__restrict__ i
 #pragma unroll
         for (int j = 0; j < NT16; j++) asm volatile("" : "+v"(acc[c][j]));
     asm volatile("s_nop 3" ::: "memory");
-    conv_passes_p<TX, NT16, PF, 0, NPASS>(acc, wbuf, pa, pb, ctx, poff);
+    conv_passes_p<TX, NT16, NTF, PF, 0, NPASS>(acc, wbuf, pa, pb, ctx, poff);
     wait_vmcnt<0>();
-    store_tiles_p<TX, NT16>(acc, out_img, out_img_bytes, om, OW, OH, Y0, X0, w, pos, g, false, 0, 0, act_floor);
+    store_tiles_p<TX, NT16>(acc, out_img, out_img_bytes, om, OW, OH, Y0, X0, w, pos, g, false, 0, 0, act_floor,
+                            (uint32_t)(split * (COUTW / 32)));
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------
-template <int NQ, int NT16, bool DECONV, int TX>
+// NT16 < NTF: output-channel split — blockIdx.y = which NT16 * 16 channels a workgroup computes.  Used on grids smaller
+// than the chip (fewer than two workgroups per CU): the tile count cannot grow, the channel dimension can; each workgroup
+// then runs the same number of passes with NT16 / NTF of the MFMAs, and the CUs that had no tile get one.
+template <int NQ, int NT16, int NTF, bool DECONV, int TX>
 static hipError_t launch_p(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images, hipStream_t stream,
                            int in_layout, int out_layout, bool relu)
 {
@@ -483,18 +496,18 @@ static hipError_t launch_p(const LayerGeom &g, const sicn_weights &w, const uint
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
     const uint32_t flags = (relu ? ACT_FLOOR_RELU : ACT_FLOOR_RAW) |
                            (nt_store_wanted((size_t)g.OH * g.OW * g.COUT * n_images) ? ACT_NT_STORE : 0u);
-    const dim3 grid(xcd_grid_size(tiles_x * tiles_y * n_images));
+    const dim3 grid(xcd_grid_size(tiles_x * tiles_y * n_images), NTF / NT16);
     if constexpr (DECONV) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_deconv_p<NQ, NT16, TX, PF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_deconv_p<NQ, NT16, NTF, TX, PF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_deconv_p<NQ, NT16, TX, PF>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias, g.IW, g.IH, g.OW,
+        hipLaunchKernelGGL((k_deconv_p<NQ, NT16, NTF, TX, PF>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias, g.IW, g.IH, g.OW,
                            g.OH, tiles_x, tiles_x * tiles_y, n_images, in_layout, out_layout, flags);
     } else {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_p<NQ, NT16, TX, PF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_p<NQ, NT16, NTF, TX, PF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_conv_p<NQ, NT16, TX, PF>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias, g.IW, g.IH, g.OW,
+        hipLaunchKernelGGL((k_conv_p<NQ, NT16, NTF, TX, PF>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias, g.IW, g.IH, g.OW,
                            g.OH, tiles_x, tiles_x * tiles_y, n_images, in_layout, out_layout, flags);
     }
     return hipGetLastError();
@@ -509,25 +522,36 @@ bool pipelined_supported(const LayerGeom &g, int tx)
 }
 
 hipError_t launch_pipelined(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images, hipStream_t stream,
-                            int in_layout, int out_layout, bool relu, int tx)
+                            int in_layout, int out_layout, bool relu, int tx, bool split)
 {
     if (!pipelined_supported(g, tx)) return hipErrorInvalidValue;
     if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB || (size_t)g.OH * g.OW * g.COUT >= (size_t)OOB) return hipErrorInvalidValue;
-#define SICN_P(NQ, NT, D, TX) return launch_p<NQ, NT, D, TX>(g, w, in, out, n_images, stream, in_layout, out_layout, relu)
+#define SICN_P(NQ, NT, NTF, D, TX) return launch_p<NQ, NT, NTF, D, TX>(g, w, in, out, n_images, stream, in_layout, out_layout, relu)
+    if (split && tx == 16) {   // 64 output channels per workgroup
+        if (g.transposed) {
+            if (g.CIN == 128 && g.COUT == 128) SICN_P(4, 4, 8, true, 16);
+            if (g.CIN == 192 && g.COUT == 128) SICN_P(6, 4, 8, true, 16);
+            if (g.CIN == 128 && g.COUT == 192) SICN_P(4, 4, 12, true, 16);
+        } else {
+            if (g.CIN == 128 && g.COUT == 128) SICN_P(4, 4, 8, false, 16);
+            if (g.CIN == 128 && g.COUT == 192) SICN_P(4, 4, 12, false, 16);
+            if (g.CIN == 192 && g.COUT == 128) SICN_P(6, 4, 8, false, 16);
+        }
+    }
     if (g.transposed) {
         if (g.CIN == 128 && g.COUT == 128) {
-            if (tx == 32) SICN_P(4, 8, true, 32);
-            SICN_P(4, 8, true, 16);
+            if (tx == 32) SICN_P(4, 8, 8, true, 32);
+            SICN_P(4, 8, 8, true, 16);
         }
-        if (g.CIN == 192 && g.COUT == 128) SICN_P(6, 8, true, 16);
-        if (g.CIN == 128 && g.COUT == 192) SICN_P(4, 12, true, 16);
+        if (g.CIN == 192 && g.COUT == 128) SICN_P(6, 8, 8, true, 16);
+        if (g.CIN == 128 && g.COUT == 192) SICN_P(4, 12, 12, true, 16);
     } else {
         if (g.CIN == 128 && g.COUT == 128) {
-            if (tx == 32) SICN_P(4, 8, false, 32);
-            SICN_P(4, 8, false, 16);
+            if (tx == 32) SICN_P(4, 8, 8, false, 32);
+            SICN_P(4, 8, 8, false, 16);
         }
-        if (g.CIN == 128 && g.COUT == 192) SICN_P(4, 12, false, 16);
-        if (g.CIN == 192 && g.COUT == 128) SICN_P(6, 8, false, 16);
+        if (g.CIN == 128 && g.COUT == 192) SICN_P(4, 12, 12, false, 16);
+        if (g.CIN == 192 && g.COUT == 128) SICN_P(6, 8, 8, false, 16);
     }
 #undef SICN_P
     return hipErrorInvalidValue;

@@ -72,7 +72,7 @@ hipError_t launch_conv128w(const LayerGeom &g, const sicn_weights &w, const uint
 // k_mfma16p.hip: the software-pipelined conv / deconv kernels (tile_x = 16 | 32)
 bool pipelined_supported(const LayerGeom &g, int tile_x);
 hipError_t launch_pipelined(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
-                            hipStream_t stream, int in_layout, int out_layout, bool relu, int tile_x);
+                            hipStream_t stream, int in_layout, int out_layout, bool relu, int tile_x, bool split_channels);
 hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
                      int n_images, hipStream_t stream, int out_layout, const sicn_options &o, bool relu = true);
 hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,

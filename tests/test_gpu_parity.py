@@ -148,6 +148,34 @@ def test_both_tile_widths_match_oracle(api, case, tile_x, prefetch):
         assert np.array_equal(got[i], ref_fn(x[i], W, b))
 
 
+@pytest.mark.parametrize("split_n", [1, 2])
+@pytest.mark.parametrize("case", MFMA_CASES + [(128, 128, 8, 16, 50, 20, 0), (192, 128, 12, 16, 37, 21, 1), (128, 192, 8, 24, 47, 18, 0),
+                                  (192, 128, 12, 16, 45, 19, 0), (128, 192, 8, 24, 21, 13, 1), (128, 128, 8, 16, 33, 9, 1)])
+def test_output_channel_split_matches_oracle(api, case, split_n):
+    """On grids smaller than the chip the pipelined kernels split a layer's output channels over 2 / 3 workgroups of 64
+    (sicn_options.split_n: 0 = by grid size, 1 = never, > 1 = always): both forms on every MFMA shape."""
+    rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + 77 * split_n)
+    d = _mk_desc(*case)
+    W, b, words = _rand_params(rng, d)
+    x = rng.integers(0, 128, (3,) + d.in_shape, dtype=np.uint8)
+    x[1].reshape(-1)[::5] |= 0x80
+    got = _run_layer(api, d, words, b, x, tile_x=16, split_n=split_n)
+    ref_fn = sicn_ref.deconv522_ref if d.transposed else sicn_ref.conv2d_ref
+    for i in range(3):
+        ref = ref_fn(x[i], W, b)
+        assert np.array_equal(got[i], ref), (i, np.count_nonzero(got[i] != ref))
+
+
+@pytest.mark.parametrize("split_n", [1, 2])
+def test_output_channel_split_in_chain(api, split_n):
+    xin = _dev(_input("rng768")[None])
+    net = api.EightLayersNet(768, 512, options={"tile_x": 16, "split_n": split_n})
+    out, latent = net.forward(xin)
+    torch.cuda.synchronize()
+    assert _sha(out[0].cpu().numpy()) == HASHES["layers"]["rng768"][7]
+    assert _sha(latent[0].cpu().numpy()) == HASHES["layers"]["rng768"][3]
+
+
 WIDE_CASES = [(128, 128, 8, 16, 66, 18, 0), (128, 128, 8, 16, 7, 5, 0), (128, 128, 8, 16, 1, 1, 0), (128, 128, 4, 32, 131, 33, 0),
               (128, 128, 8, 16, 50, 20, 0), (128, 128, 8, 16, 200, 90, 0), (128, 128, 8, 16, 129, 67, 0)]
 
