@@ -15,6 +15,7 @@
 // offsets, and a copy kernel compacts the streams into the container.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -66,6 +67,16 @@ size_t carve(Workspace &w, void *base, uint32_t ns, size_t scratch_per_stream)
     return off;
 }
 
+// k_stats grid: at most 128 workgroups per image — each ends with up to 256 global atomics on the SAME 256 words, and those
+// serialise in L2.  Measured r02 (tools/coder_speed.py, encode of a 1080p / of 8 4K latents): 32 workgroups 78 / 146 us,
+// 128: 80 / 126, 512: 103 / 215.  (Per-workgroup partial histograms summed by the last workgroup to finish were slower
+// still: 91 / 203 us — one workgroup walking 128 rows is a serial chain of its own.)
+static inline unsigned stats_blocks(uint32_t n, uint32_t n_images)
+{
+    (void)n_images;
+    return std::min((n / 16 + 255u) / 256u + 1u, 128u);
+}
+
 // ---- kernels ----------------------------------------------------------------------------------
 // histogram (256 bins) + the two sums adler32 is made of; grid-stride over 16-byte groups (consecutive lanes read
 // consecutive groups); zeros — half of a ReLU latent — are counted in a register instead of hammering one LDS bin
@@ -88,8 +99,12 @@ __global__ __launch_bounds__(256) void k_stats(const uint8_t *__restrict__ lat_,
     const uint8_t *lat = img_ptr(lat_, s_lat);
     uint32_t *hist = img_ptr(hist_, s_ws);
     unsigned long long *sums = img_ptr(sums_, s_ws);
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+    // 8 copies of the histogram, copy = lane & 7, at a pitch of 257 words: latents are skewed (a few small values carry most
+    // of the mass), so lanes of one wave mostly hit the SAME bin — with one copy those LDS atomics serialise; copies of a bin
+    // sit in 8 different banks
+    __shared__ uint32_t h[8 * 257];
+    for (int i = threadIdx.x; i < 8 * 257; i += 256) h[i] = 0;
+    uint32_t *hl = h + (threadIdx.x & 7) * 257;
     __syncthreads();
     unsigned long long s1 = 0, s2 = 0;
     uint32_t zeros = 0;
@@ -102,7 +117,7 @@ __global__ __launch_bounds__(256) void k_stats(const uint8_t *__restrict__ lat_,
         for (int k = 0; k < 16; k++) {
             const uint32_t d = (w4[k >> 2] >> (8 * (k & 3))) & 255u;
             if (d) {
-                atomicAdd(&h[d], 1u);
+                atomicAdd(&hl[d], 1u);
                 s1 += d;
                 s2 += (unsigned long long)(n - (16 * g + k)) * d;   // < 2^39 per term, far fewer than 2^25 terms per lane
             } else
@@ -112,7 +127,7 @@ __global__ __launch_bounds__(256) void k_stats(const uint8_t *__restrict__ lat_,
     for (uint32_t i = 16 * groups + blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const uint32_t d = lat[i];
         if (d) {
-            atomicAdd(&h[d], 1u);
+            atomicAdd(&hl[d], 1u);
             s1 += d;
             s2 += (unsigned long long)(n - i) * d;
         } else
@@ -128,11 +143,14 @@ __global__ __launch_bounds__(256) void k_stats(const uint8_t *__restrict__ lat_,
     }
     if ((threadIdx.x & 63) == 0 && zeros) atomicAdd(&h[0], zeros);
     __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+    uint32_t total = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) total += h[c * 257 + threadIdx.x];
     if ((threadIdx.x & 63) == 0) {
         if (s1) atomicAdd(&sums[0], s1);
         if (s2) atomicAdd(&sums[1], s2 % ADLER_MOD);
     }
+    if (total) atomicAdd(&hist[threadIdx.x], total);
 }
 
 // ---- rANS-W: one wave (= one 64-lane workgroup) per stream -----------------------------------------
@@ -270,7 +288,7 @@ __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__
                                                      const uint32_t *__restrict__ offsets_, uint32_t n, uint32_t ns,
                                                      uint8_t *__restrict__ lat_, uint32_t *__restrict__ err_, size_t s_slot,
                                                      size_t s_ws, size_t s_lat, const uint8_t *__restrict__ payload_bytes_field_,
-                                                     const uint32_t *__restrict__ meta_)
+                                                     const uint32_t *__restrict__ meta_, unsigned long long *__restrict__ sums_ = nullptr)
 {
     const uint8_t *payload = img_ptr(payload_, s_slot), *freq_bytes = img_ptr(freq_bytes_, s_slot);
     // header field "payload bytes" of this image's container (the host has checked it against the bytes it was
@@ -311,6 +329,9 @@ __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__
     const unsigned long long below = (1ull << lane) - 1;
     const bool aligned = (reinterpret_cast<uintptr_t>(lat) & 3) == 0;
     bool bad = false;
+    // sums_ (async path): the two sums adler32 is made of, taken from the symbols as they are decoded — the separate
+    // statistics pass over the decoded latent (17 us on a 1080p latent, a tenth of a small image's whole decode) goes away
+    unsigned long long s1 = 0, s2 = 0;
     for (uint32_t q = 0; q < blocks; q++) {
         if (loaded < nwords && loaded - min(wpos, loaded) < 4 * 64) {   // top the ring up: the 4 steps below read <= 256 words
             __syncthreads();
@@ -325,6 +346,8 @@ __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__
                 const uint32_t v = x & 4095u, sy = slot[v], t = tab.fc[sy];
                 out4 |= sy << (8 * k);
                 x = (t & 0xFFFFu) * (x >> PROB_BITS) + v - (t >> 16);
+                s1 += sy;
+                s2 += (unsigned long long)(n - (begin + q * 256 + lane * 4 + k)) * sy;   // < 2^38 per term, 1024 terms per lane
             }
             const bool need = active && x < RANSW_L;
             const unsigned long long mask = __ballot(need);
@@ -345,6 +368,19 @@ __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__
                 if (j + k < cnt) lat[begin + j + k] = (uint8_t)(out4 >> (8 * k));
     }
     if (bad || x != RANSW_L || wpos != nwords) atomicOr(err, 1u);
+    if (sums_) {
+        unsigned long long *sums = img_ptr(sums_, s_ws);
+        s2 %= ADLER_MOD;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            s1 += __shfl_down(s1, d);
+            s2 += __shfl_down(s2, d);
+        }
+        if (lane == 0) {
+            if (s1) atomicAdd(&sums[0], s1);
+            if (s2) atomicAdd(&sums[1], s2 % ADLER_MOD);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_rans_encode(const uint8_t *__restrict__ lat, uint32_t n, uint32_t ns,
@@ -525,10 +561,19 @@ __global__ __launch_bounds__(256) void k_unpack7(const uint8_t *__restrict__ in,
 // ---- asynchronous batch path: everything the host did between two synchronisations, on the device -----------
 // blockIdx.y = image everywhere; per-image workspace stride s_ws, container slot stride s_slot.
 
+constexpr uint32_t STATS_WORDS = (1024 + 64 + 256) / 4;   // hist[256] + sums (64 B) + freq (256 B), then meta (64 B): contiguous
 __global__ __launch_bounds__(64) void k_clear_stats(uint32_t *__restrict__ hist_, size_t s_ws)
 {
-    uint32_t *h = img_ptr(hist_, s_ws);   // hist[256] + sums (64 B) + freq (256 B) + meta (64 B) are contiguous
-    for (uint32_t i = threadIdx.x; i < (1024 + 64 + 256 + 64) / 4; i += 64) h[i] = 0;
+    uint32_t *h = img_ptr(hist_, s_ws);
+    for (uint32_t i = threadIdx.x; i < STATS_WORDS + 16; i += 64) h[i] = 0;
+}
+// the decoders' parse kernels are the first thing on the stream that touches the workspace: they clear the block themselves
+// (one launch less, about 4.5 us of a small image's decode) — everything but meta[0..3], which lane 0 then writes
+__device__ __forceinline__ void clear_stats_in_parse(uint32_t *meta, int lane)
+{
+    uint32_t *h = meta - STATS_WORDS;
+    for (uint32_t i = lane; i < STATS_WORDS + 16; i += 64)
+        if (i < STATS_WORDS || i >= STATS_WORDS + 4) h[i] = 0;
 }
 
 // Histogram -> 12-bit frequencies exactly as `normalize` / sicl_or_normalize do it (same floor, same "largest first,
@@ -608,8 +653,9 @@ __global__ __launch_bounds__(64) void k_dec_parse(const uint8_t *__restrict__ co
                                         : (uint32_t)min(s_slot, (size_t)0xFFFFFFFFu);
     const size_t fixed = SICN_CODEC_HEADER_BYTES + 256 + 4 * (size_t)ns;
     uint32_t err = 0;
+    clear_stats_in_parse(meta, lane);
     if (valid < fixed) {   // nothing of this slot may be read
-        if (lane == 0) { meta[0] = 0x104u; meta[1] = 0; meta[2] = 0; }
+        if (lane == 0) { meta[0] = 0x104u; meta[1] = 0; meta[2] = 0; meta[3] = 0; }
         return;
     }
     auto rd32 = [&](int o) { return c[o] | ((uint32_t)c[o + 1] << 8) | ((uint32_t)c[o + 2] << 16) | ((uint32_t)c[o + 3] << 24); };
@@ -628,6 +674,7 @@ __global__ __launch_bounds__(64) void k_dec_parse(const uint8_t *__restrict__ co
         meta[0] = err;
         meta[1] = (err & 16) ? 0u : pb;
         meta[2] = rd32(44);
+        meta[3] = 0;
     }
 }
 
@@ -784,7 +831,8 @@ extern "C" int sicn_codec_encode(int mode, const uint8_t *latent, uint32_t lat_w
 
     // statistics (also the checksum and the symbol-range check) -------------------------------
     HIP_TRY(hipMemsetAsync(w.hist, 0, 1024 + 64, stream));
-    if (n) hipLaunchKernelGGL(k_stats, dim3(min((n / 16 + 255u) / 256u + 1u, 128u)), dim3(256), 0, stream, latent, n, w.hist, w.sums, (size_t)0, (size_t)0);
+    if (n)
+        hipLaunchKernelGGL(k_stats, dim3(stats_blocks(n, 1)), dim3(256), 0, stream, latent, n, w.hist, w.sums, (size_t)0, (size_t)0);
     uint32_t hist[256];
     unsigned long long sums[2];
     HIP_TRY(hipMemcpyAsync(hist, w.hist, sizeof hist, hipMemcpyDeviceToHost, stream));
@@ -910,7 +958,7 @@ extern "C" int sicn_codec_decode(const uint8_t *container, size_t bytes, uint8_t
     HIP_TRY(hipStreamSynchronize(stream));
     if (flag) return SICN_EINVAL;
     HIP_TRY(hipMemsetAsync(w.hist, 0, 1024 + 64, stream));
-    if (n) hipLaunchKernelGGL(k_stats, dim3(min((n / 16 + 255u) / 256u + 1u, 128u)), dim3(256), 0, stream, latent, n, w.hist, w.sums, (size_t)0, (size_t)0);
+    if (n) hipLaunchKernelGGL(k_stats, dim3(stats_blocks(n, 1)), dim3(256), 0, stream, latent, n, w.hist, w.sums, (size_t)0, (size_t)0);
     unsigned long long sums[2];
     HIP_TRY(hipMemcpyAsync(sums, w.sums, sizeof sums, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -951,7 +999,7 @@ extern "C" int sicn_codec_encode_batch_async(const uint8_t *latents, uint32_t n_
     const uint32_t fixed = (uint32_t)(SICN_CODEC_HEADER_BYTES + 256 + 4 * (size_t)ns);
     hipLaunchKernelGGL(k_clear_stats, dim3(1, n_images), dim3(64), 0, stream, w.hist, ws1);
     if (n)
-        hipLaunchKernelGGL(k_stats, dim3(min((n / 16 + 255u) / 256u + 1u, 128u), n_images), dim3(256), 0, stream, latents, n, w.hist,
+        hipLaunchKernelGGL(k_stats, dim3(stats_blocks(n, n_images), n_images), dim3(256), 0, stream, latents, n, w.hist,
                            w.sums, (size_t)n, ws1);
     hipLaunchKernelGGL(k_enc_header, dim3(1, n_images), dim3(64), 0, stream, w.hist, w.sums, w.freq, out, status, n, ns, lat_w,
                        lat_h, lat_c, img_w, img_h, ws1, slot_bytes);
@@ -983,7 +1031,6 @@ extern "C" int sicn_codec_decode_batch_async(const uint8_t *containers, size_t s
     Workspace w;
     carve(w, workspace, ns, 0);
     const uint8_t *freq_bytes = containers + SICN_CODEC_HEADER_BYTES, *table = freq_bytes + 256, *payload = table + 4 * (size_t)ns;
-    hipLaunchKernelGGL(k_clear_stats, dim3(1, n_images), dim3(64), 0, stream, w.hist, ws1);
     hipLaunchKernelGGL(k_dec_parse, dim3(1, n_images), dim3(64), 0, stream, containers,
                        valid_dev_or_null ? &valid_dev_or_null->bytes : (const uint32_t *)nullptr, 2u, w.meta, n, ns, lat_w, lat_h,
                        lat_c, slot_bytes, ws1);
@@ -994,10 +1041,7 @@ extern "C" int sicn_codec_decode_batch_async(const uint8_t *containers, size_t s
                        (const uint32_t *)w.meta);
     if (ns)
         hipLaunchKernelGGL(k_ransw_decode, dim3(ns, n_images), dim3(64), 0, stream, payload, freq_bytes, w.offsets, n, ns, latents,
-                           w.meta + 3, slot_bytes, ws1, latent_stride, containers + 40, w.meta);
-    if (n)
-        hipLaunchKernelGGL(k_stats, dim3(min((n / 16 + 255u) / 256u + 1u, 128u), n_images), dim3(256), 0, stream, latents, n, w.hist,
-                           w.sums, latent_stride, ws1);
+                           w.meta + 3, slot_bytes, ws1, latent_stride, containers + 40, w.meta, w.sums);
     hipLaunchKernelGGL(k_dec_finish, dim3(1, n_images), dim3(64), 0, stream, w.meta, w.hist, w.sums, w.offsets, (uint32_t *)status_dev,
                        n, ns, ws1);
     return hipGetLastError() == hipSuccess ? SICN_OK : SICN_ENODEV;
