@@ -50,6 +50,11 @@ int sicn_deconv522_gdn(const sicn_layer_desc *desc, const sicn_weights *w, const
 int sicn_net_create_gdn(const sicn_layer_desc *descs, sicn_weights *const *weights, const sicn_gdn *const *gdn,
                         int n_layers, const sicn_options *opt, sicn_net **out);
 
+/* Test hook: the kernels' two integer roots — floor(2^16 / sqrt(n)) (inverse = 0) and floor(2^8 sqrt(n)) (inverse = 1), which
+ * the device code gets from a float estimate and an integer fix-up — against integer bisection, on the device, for every
+ * n in [n_begin, n_begin + count).  Synchronous.  Returns the number of n whose root differs (0 = exact), < 0 on error. */
+long long sicn_gdn_selftest_roots(int inverse, uint32_t n_begin, unsigned long long count);
+
 #ifdef __cplusplus
 }
 #endif

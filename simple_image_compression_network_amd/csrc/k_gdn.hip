@@ -21,34 +21,67 @@
 
 namespace sicn {
 
-// r = max{ r : r^2 n <= 2^32 } = floor(2^16 / sqrt(n)), 1 <= n < 2^30.  Float estimate r0 (cvt + v_rsq_f32 are good to < 2^-21
-// relative, r <= 46341 for n >= 2: |r0 - r| <= 1) and a BRANCH-FREE exact fix-up: ok(q) = [q^2 n <= 2^32] is monotone, so
-// r = r0 - 1 + ok(r0) + ok(r0 + 1).  (Round 2's first version looped on ok(): the data-dependent branches cost more than the
-// arithmetic — 387 s_cbranch in the kernel.)
+// The kernel is VALU-bound on these two roots (r02: 55 instructions per element, 5 - 9 of them quarter-rate 32-bit
+// multiplies), so they are written for instruction count; tests/test_gdn.py checks both against integer bisection for EVERY
+// n < 2^31 on the device (sicn_gdn_selftest_roots).
+//
+// r = max{ r : r^2 n <= 2^32 } = floor(2^16 / sqrt(n)), 1 <= n < 2^31.  t = 2^16 / sqrt(n) in float: cvt (2^-24) and
+// v_rsq_f32 (1 ulp) leave a relative error below 2^-22, i.e. < 0.012 absolute for t <= 46341 (n >= 2).  With q = floor(t~ + 0.05)
+// the true floor is q or q - 1, and ONE exact test decides: r = q - 1 + [q^2 n <= 2^32].  q < 2^24, so q^2 is a full-rate
+// 24-bit multiply; the 64-bit product costs the two slow ones.
 __device__ __forceinline__ uint32_t gdn_rsqrt16(uint32_t n)
 {
-    uint32_t r0 = (uint32_t)(65536.0f * __frsqrt_rn((float)n));
-    r0 = max(1u, min(r0, 65534u));
-    auto ok = [&](uint32_t q) -> uint32_t {   // q <= 65535: q^2 fits 32 bits
-        const uint32_t q2 = q * q, lo = q2 * n, hi = __umulhi(q2, n);
-        return (hi == 0 || (hi == 1 && lo == 0)) ? 1u : 0u;
-    };
-    const uint32_t r = r0 - 1 + ok(r0) + ok(r0 + 1);
+    uint32_t q = (uint32_t)(65536.0f * __frsqrt_rn((float)n) + 0.05f);
+    q = max(1u, min(q, 65535u));
+    const unsigned long long prod = (unsigned long long)(uint32_t)__umul24(q, q) * n;   // one v_mad_u64_u32 (__umul24 returns int)
+    const uint32_t r = q - (prod > (1ull << 32) ? 1u : 0u);
     return n <= 1 ? 65536u : r;
 }
 
-// r = max{ r : r^2 <= n 2^16 } = floor(2^8 sqrt(n)), n < 2^30 (r < 2^23): the float estimate is within 2 (relative 2^-21 of up to
-// 5.9e6), so r = r0 - 2 + ok(r0 - 1) + ok(r0) + ok(r0 + 1) + ok(r0 + 2) with ok(q) = [q^2 <= n 2^16] (64-bit compare).
+// r = max{ r : r^2 <= n 2^16 } = floor(2^8 sqrt(n)), n < 2^31 (r < 2^23.6).  The float estimate r0 is within 2 of it (relative
+// 2^-22.6 of up to 1.2e7), so r = r0 - 2 + sum_{k=-1..2} [(r0 + k)^2 <= N], N = n 2^16.  With d = N - r0^2 the tests read
+// 2 k r0 + k^2 <= d, and |d| < 2^27: d is exact in the LOW 32 bits of N and of r0^2 (one 24-bit multiply) — no 64-bit
+// arithmetic, no slow multiply at all.
 __device__ __forceinline__ uint32_t gdn_sqrt8(uint32_t n)
 {
-    const uint32_t nlo = n << 16, nhi = n >> 16;
     uint32_t r0 = (uint32_t)(256.0f * __fsqrt_rn((float)n));
     r0 = max(r0, 2u);
-    auto ok = [&](uint32_t q) -> uint32_t {
-        const uint32_t lo = q * q, hi = __umulhi(q, q);
-        return (hi < nhi || (hi == nhi && lo <= nlo)) ? 1u : 0u;
-    };
-    return r0 - 2 + ok(r0 - 1) + ok(r0) + ok(r0 + 1) + ok(r0 + 2);
+    const int d = (int)((n << 16) - __umul24(r0, r0));
+    const int r2 = (int)(2u * r0);
+    return r0 - 2 + (1 - r2 <= d ? 1u : 0u) + (0 <= d ? 1u : 0u) + (r2 + 1 <= d ? 1u : 0u) + (2 * r2 + 4 <= d ? 1u : 0u);
+}
+
+// exact references for the self-test: integer bisection, as in oracle/sicn_gdn_oracle.c
+__device__ uint32_t gdn_rsqrt16_slow(uint32_t n)
+{
+    unsigned long long lo = 0, hi = 65536;
+    while (lo < hi) {
+        const unsigned long long mid = (lo + hi + 1) >> 1;
+        if (mid * mid * (unsigned long long)n <= (1ull << 32)) lo = mid; else hi = mid - 1;
+    }
+    return (uint32_t)lo;
+}
+__device__ uint32_t gdn_sqrt8_slow(uint32_t n)
+{
+    const unsigned long long v = (unsigned long long)n << 16;
+    unsigned long long lo = 0, hi = 1ull << 24;
+    while (lo < hi) {
+        const unsigned long long mid = (lo + hi + 1) >> 1;
+        if (mid * mid <= v) lo = mid; else hi = mid - 1;
+    }
+    return (uint32_t)lo;
+}
+__global__ __launch_bounds__(256) void k_gdn_selftest(uint32_t n_begin, unsigned long long count, int inverse,
+                                                       unsigned long long *__restrict__ bad)
+{
+    unsigned long long mine = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * 256) {
+        const uint32_t n = n_begin + (uint32_t)i;
+        if (!inverse && n == 0) continue;   // GDN: n >= 1 (beta >= 1)
+        const uint32_t fast = inverse ? gdn_sqrt8(n) : gdn_rsqrt16(n), slow = inverse ? gdn_sqrt8_slow(n) : gdn_rsqrt16_slow(n);
+        mine += fast != slow;
+    }
+    if (mine) atomicAdd(bad, mine);
 }
 
 template <bool INVERSE>
@@ -80,19 +113,47 @@ __global__ __launch_bounds__(256, 2) void k_gdn(uint8_t *__restrict__ data, cons
 
     uint8_t *img = data + (size_t)blockIdx.y * (size_t)image_bytes;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, (int)image_bytes, 0x00020000);
-    for (uint32_t blk = blockIdx.x; blk < (uint32_t)blocks_per_image; blk += gridDim.x) {
+    // items = (block of 256 positions, quarter c): a wave's 16 positions x C channels per item.  The NEXT item's chunks are
+    // requested before the current one is worked on, so the (HBM-latency) load hides behind ~10k cycles of arithmetic.
+    auto locate = [&](uint32_t blk, int c, uint32_t &base, bool &okp) {
+        const uint32_t p = blk * 256u + (uint32_t)(w * 64 + c * 16 + pos);
+        okp = p < n_pos;
+        const uint32_t pl = p / map.P, pr = p - pl * map.P;
+        base = pl * map.plane + pr * map.pix;
+    };
+    auto chunk_off = [&](uint32_t base, bool okp, int J) -> uint32_t {   // chunk k = 4 J + g: channels 64 J + 16 g .. + 15
+        const uint32_t k = (uint32_t)(4 * J + g);
+        return okp ? base + (k >> 1) * map.grp + (k & 1u) * 16u : OOB;
+    };
+    uint32_t blk = blockIdx.x, base_n = 0;
+    int c = 0;
+    bool ok_n = false, have = blk < (uint32_t)blocks_per_image;
+    v4i xn[NJ];
+    if (have) {
+        locate(blk, 0, base_n, ok_n);
+#pragma unroll
+        for (int J = 0; J < NJ; J++) xn[J] = __builtin_amdgcn_raw_buffer_load_b128(rs, chunk_off(base_n, ok_n, J), 0, 0);
+    }
 #pragma unroll 1
-        for (int c = 0; c < 4; c++) {
-            const uint32_t p = blk * 256u + (uint32_t)(w * 64 + c * 16 + pos);
-            const bool okp = p < n_pos;
-            const uint32_t pl = p / map.P, pr = p - pl * map.P;
-            const uint32_t base = pl * map.plane + pr * map.pix;
+    while (have) {
+        {
+            const uint32_t base = base_n;
+            const bool okp = ok_n;
             v4i xf[NJ], hf[NJ], lf[NJ];
 #pragma unroll
-            for (int J = 0; J < NJ; J++) {   // chunk k = 4 J + g: channels 64 J + 16 g .. + 15
-                const uint32_t k = (uint32_t)(4 * J + g);
-                const uint32_t off = okp ? base + (k >> 1) * map.grp + (k & 1u) * 16u : OOB;
-                xf[J] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+            for (int J = 0; J < NJ; J++) xf[J] = xn[J];
+            if (++c == 4) {
+                c = 0;
+                blk += gridDim.x;
+            }
+            have = blk < (uint32_t)blocks_per_image;
+            if (have) {
+                locate(blk, c, base_n, ok_n);
+#pragma unroll
+                for (int J = 0; J < NJ; J++) xn[J] = __builtin_amdgcn_raw_buffer_load_b128(rs, chunk_off(base_n, ok_n, J), 0, 0);
+            }
+#pragma unroll
+            for (int J = 0; J < NJ; J++) {
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
                     uint32_t h = 0, l = 0;
@@ -142,9 +203,7 @@ __global__ __launch_bounds__(256, 2) void k_gdn(uint8_t *__restrict__ data, cons
                     }
                     y[d] = (int)packed;
                 }
-                const uint32_t k = (uint32_t)(4 * J + g);
-                const uint32_t off = okp ? base + (k >> 1) * map.grp + (k & 1u) * 16u : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(y, rs, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(y, rs, chunk_off(base, okp, J), 0, 0);
             }
         }
     }
@@ -232,6 +291,21 @@ hipError_t launch_gdn_generic(const sicn_gdn &g, uint8_t *data, long long n_pos,
     hipLaunchKernelGGL(k_gdn_generic, dim3((unsigned)blocks), dim3(256), 0, stream, data, g.d_gamma, g.d_beta, n_pos, g.channels,
                        g.inverse, g.shift, ppb);
     return hipGetLastError();
+}
+
+hipError_t gdn_selftest_roots(int inverse, uint32_t n_begin, unsigned long long count, unsigned long long *mismatches)
+{
+    unsigned long long *d_bad = nullptr;
+    hipError_t e = hipMalloc(&d_bad, 8);
+    if (e != hipSuccess) return e;
+    e = hipMemset(d_bad, 0, 8);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_gdn_selftest, dim3(4096), dim3(256), 0, nullptr, n_begin, count, inverse, d_bad);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(mismatches, d_bad, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad);
+    return e;
 }
 
 }  // namespace sicn

@@ -539,6 +539,14 @@ extern "C" void sicn_gdn_free(sicn_gdn *g)
     delete g;
 }
 
+extern "C" long long sicn_gdn_selftest_roots(int inverse, uint32_t n_begin, unsigned long long count)
+{
+    if ((inverse != 0 && inverse != 1) || (unsigned long long)n_begin + count > (1ull << 31)) return SICN_EINVAL;
+    unsigned long long bad = 0;
+    if (sicn::gdn_selftest_roots(inverse, n_begin, count, &bad) != hipSuccess) return SICN_ENODEV;
+    return (long long)bad;
+}
+
 extern "C" int sicn_gdn_create(int channels, int inverse, int shift, const uint32_t *beta, const uint8_t *gamma, sicn_gdn **out)
 {
     if (!out) return SICN_EINVAL;

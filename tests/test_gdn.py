@@ -153,6 +153,20 @@ def test_gpu_gdn_square_roots_exhaustive_ranges():
                 assert np.array_equal(got, c_oracle.gdn(xs, b, gm, inverse, 9)), (inverse, gam, int(beta))
 
 
+@gpu
+@pytest.mark.parametrize("inverse", [0, 1])
+def test_gpu_gdn_roots_exact_for_every_n(inverse):
+    """sicn_gdn_selftest_roots: the float-estimate + integer-fix-up roots of the kernels against integer bisection ON THE
+    DEVICE for EVERY n the specification admits and beyond (n < 2^31; the MFMA kernels see n < 2^29, the generic one
+    n < 2^16 + 1024 * 127 * 16129 < 2^31).  0 mismatches = the kernels' arithmetic is exact, not merely exact on samples."""
+    from simple_image_compression_network_amd import _lib
+    L = _lib.lib()
+    step = 1 << 28
+    for begin in range(0, 1 << 31, step):
+        assert L.sicn_gdn_selftest_roots(inverse, begin, step) == 0, (inverse, begin)
+    assert L.sicn_gdn_selftest_roots(inverse, 0, (1 << 31) + 1) == -22
+
+
 # every kernel family that can carry a GDN: l0_rgb, mfma_conv (128 and 192 out), mfma_deconv, generic (incl. the RGB-out
 # layer, which the library routes to the generic kernel when it has a GDN)
 GDN_LAYERS = [(3, 128, 3, 8, 70, 38, 0), (128, 128, 8, 16, 66, 18, 0), (128, 192, 8, 24, 40, 22, 0), (192, 128, 12, 16, 33, 9, 1),
