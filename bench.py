@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-coder", action="store_true", help="skip the secondary with_coder measurement")
     ap.add_argument("--no-hyperprior", action="store_true", help="skip the secondary hyperprior (configs[4]) measurement")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the secondary host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--cpu-sample", type=int, nargs=2, default=[256, 256], metavar=("W", "H"))
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank) is the real thing; gloo lets several ranks share one GPU "
@@ -251,6 +252,36 @@ def main():
                  "note": "BASELINE.json configs[4]; no reference counterpart (SURVEY.md section 0): parity unpinned, seeded random "
                          "hyper / GDN parameters"}
         del hc, out_h2, direct
+    # ---- secondary: the same step with HOST buffers on both sides (pinned memory, upload / compute / download streams) ----
+    pcie = None
+    if not args.no_host_io and rank == 0 and world == 1:
+        from simple_image_compression_network_amd.host_pipeline import HostPipeline
+        hp = HostPipeline(net, B, depth=2, want_latent=True)
+        nb = 3                                               # distinct host batches in flight (the data repeats: synthetic)
+        h_in = [HostPipeline.pinned(x.shape) for _ in range(nb)]
+        h_out = [HostPipeline.pinned(out.shape) for _ in range(nb)]
+        h_lat = [HostPipeline.pinned(latent.shape) for _ in range(nb)]
+        for t in h_in:
+            t.copy_(x)
+        torch.cuda.synchronize()
+        psteps = max(3, args.steps)
+        idx = [i % nb for i in range(psteps)]
+        hp.run([h_in[i] for i in idx[:nb]], [h_out[i] for i in idx[:nb]], [h_lat[i] for i in idx[:nb]])   # warm-up
+        hp.synchronize()
+        t0 = time.perf_counter()
+        hp.run([h_in[i] for i in idx], [h_out[i] for i in idx], [h_lat[i] for i in idx])
+        hp.synchronize()
+        pdt = time.perf_counter() - t0
+        same = all((zlib.adler32(t.numpy().reshape(-1)) & 0xFFFFFFFF) == rank_checksums[rank] for t in h_out)
+        step_bytes = x.numel() + out.numel() + latent.numel()
+        pcie = {"value": round(B * W * H * psteps / pdt / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(pdt / psteps * 1e3, 3),
+                "steps": psteps, "host_bytes_per_step": int(step_bytes),
+                "pcie_GBs_each_way": round(max(x.numel(), out.numel() + latent.numel()) * psteps / pdt / 1e9, 1),
+                "outputs_equal_resident_run": bool(same),
+                "path": "pinned host batch -> H2D stream -> eight_layers_net on the compute stream -> D2H stream (reconstruction + "
+                        "latent), 2 device slots, events between the three streams (host_pipeline.HostPipeline)",
+                "note": "never `value`: the headline is HBM-resident; this is the rate a caller that owns host streams sees"}
+        del hp, h_in, h_out, h_lat
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
@@ -311,7 +342,12 @@ def main():
         "roofline": roof, "layers": layers,
         "device_ms_sum_per_step": round(sum(avg_ms), 3),
         "whole_net_mfma_frac": round(net_ops / (dt / args.steps) / 1e12 / PEAK_INT8_TOPS, 4),
+        # SURVEY.md 8(d), the memory view: layer-wise algorithmic bytes (every activation written once and read once)
+        "whole_net_hbm_frac": round(sum(l["GBs"] * l["ms"] * 1e-3 for l in layers) / (dt / args.steps) / PEAK_HBM_GBS, 4)
+        if all("GBs" in l for l in layers) else None,
     }
+    if pcie is not None:
+        res["host_io"] = pcie
     if with_coder is not None:
         res["with_coder"] = with_coder
     if hyper is not None:
