@@ -22,7 +22,11 @@ Rank 0 prints ONE JSON line:
                         the reference has none), timed the same way
   cpu_baseline          the oracle's dataflow-faithful C port (1 thread, crop) — the stand-in for the reference's HLS
                         C-simulation, which needs Vivado headers — plus `all_cores`: the oracle's OpenMP direct form
-                        on one whole 4K image, whose bytes are also compared with the GPU's image 0
+                        on one whole 4K image, whose bytes are also compared with the GPU's image 0, plus `reference`:
+                        the reference's own golden convolution (conv.hpp, compiled unmodified into oracle/_ref in the
+                        build container; the built library travels, the sources do not) on a 256 x 256 crop
+  host_io               secondary: the same step from and to pinned HOST buffers (PCIe-inclusive; never `value`)
+  hyperprior            secondary: BASELINE.json configs[4] (GDN / IGDN, hyper stacks, conditional coder)
 """
 from __future__ import annotations
 
@@ -102,6 +106,22 @@ def cpu_baseline(image0: np.ndarray, sample_wh, gpu_latent0, gpu_out0):
                         "kind": "port", "sample": f"whole image 0 ({W}x{H}), all 8 layers, oracle direct closed form, "
                                                   f"OpenMP {nproc} threads, gcc -O3, {dt:.1f} s",
                         "gpu_image0_equals_cpu": bool(np.array_equal(outs[3], gpu_latent0) and np.array_equal(outs[7], gpu_out0))}
+    # the reference's OWN CPU model where its build travelled with the snapshot: conv_nonsquare<> of the reference's conv.hpp,
+    # compiled unmodified in the build container (oracle/_ref, `make -C oracle ref`), all 8 layers of a 256 x 256 crop layer by
+    # layer as the reference's testbench runs it (conv3_nonsquare_tb.cpp:861-1056); timed inside the reference code only
+    from oracle import ref_conv
+    if ref_conv.available():
+        from simple_image_compression_network_amd.config import NET_CHANNELS
+        crop256 = np.ascontiguousarray(image0[:256, :256])
+        routs, rsec = ref_conv.run_net(ref_conv.NET_256, crop256, words, bias, NET_CHANNELS)
+        port = c_oracle.run_net(eight_layer_descs(256, 256), words, bias, crop256, "direct", threads=nproc)
+        res["reference"] = {"value": round(256 * 256 / rsec / 1e6, 6), "unit": "Mpixels/s", "cores": 1, "kind": "reference",
+                            "sample": f"top-left 256x256 crop of image 0, all 8 layers through the reference's conv_nonsquare<> "
+                                      f"(conv.hpp:91-123 compiled unmodified, g++ -O2, oracle/_ref), 1 thread, {rsec:.1f} s "
+                                      f"inside the reference code",
+                            "equals_oracle": bool(all(np.array_equal(a, b) for a, b in zip(routs, port)))}
+    else:
+        res["reference"] = None   # oracle/_ref is built only where /root/reference exists (build container); see oracle/Makefile
     return res
 
 

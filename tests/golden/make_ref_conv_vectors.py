@@ -25,7 +25,6 @@ What is reference code here and what is restated:
 The dataflow half of the oracle (sliding-window FSM, MVAU fold order) has no reference-compiled anchor:
 conv_nonsquare_top.cpp needs the Vivado-HLS headers.
 """
-import ctypes
 import hashlib
 import json
 import sys
@@ -40,81 +39,7 @@ ROOT = HERE.parent.parent
 sys.path.insert(0, str(ROOT))
 from simple_image_compression_network_amd.config import LayerDesc, NET_CHANNELS  # noqa: E402
 
-LIB = ctypes.CDLL(str(ROOT / "oracle" / "_ref" / "libsicn_refconv.so"))
-LIB.sicn_refconv_dims.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
-LIB.sicn_refconv_run.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4
-
-
-def _dims(case_id):
-    d = (ctypes.c_int * 7)()
-    assert LIB.sicn_refconv_dims(case_id, d) == 0, case_id
-    return tuple(d)
-
-
-def padded_map(x, transposed):
-    """x [H][W][C] -> the testbench's input_padding[x][y][c] (index order x FIRST).
-    conv (tb:581-600): 2-pixel zero border.  deconv (tb:700-718): size 2W+4 x 2H+4, zero where
-    ox < 2 | ox >= 2W+2 | (ox-1) even (same for y), else input[(ox-2)/2][(oy-2)/2]."""
-    h, w, c = x.shape
-    if not transposed:
-        p = np.zeros((w + 4, h + 4, c), np.uint8)
-        p[2:2 + w, 2:2 + h] = x.transpose(1, 0, 2)
-        return p
-    p = np.zeros((2 * w + 4, 2 * h + 4, c), np.uint8)
-    for ox in range(2 * w + 4):
-        if ox < 2 or ox >= 2 * w + 2 or (ox + 1 - 2) % 2 == 0:
-            continue
-        for oy in range(2 * h + 4):
-            if oy < 2 or oy >= 2 * h + 2 or (oy + 1 - 2) % 2 == 0:
-                continue
-            p[ox, oy] = x[(oy - 2) // 2, (ox - 2) // 2]
-    return p
-
-
-def tb_unpack_weights(words, simd, pe, cin, cout):
-    """conv3_nonsquare_tb.cpp:546-571 transcribed: words[PE][TILES] -> W[o][kx][ky][c] (int8).
-    `weights(tile)[pe][simd]` = sign-extended nibble `simd` of m_weights[pe][tile] (weights.hpp:134-139)."""
-    tx, ty = (cin * 25) // simd, cout // pe
-    W = np.zeros((cout, 5, 5, cin), np.int8)
-    kx = ky = chan = 0
-    for p in range(pe):
-        o = p
-        for oy in range(ty):
-            for ox in range(tx):
-                word = int(words[p][oy * tx + ox])
-                for s in range(simd):
-                    n = (word >> (4 * s)) & 15
-                    W[o, kx, ky, chan] = n - 16 if n > 7 else n
-                    chan += 1
-                    if chan == cin:
-                        chan = 0
-                        kx += 1
-                        if kx == 5:
-                            kx = 0
-                            ky += 1
-                            if ky == 5:
-                                ky = 0
-                                o += pe
-                                if o == cout:
-                                    o = 0
-    return W
-
-
-def ref_layer(case_id, x, words, bias, simd, pe, transposed):
-    """One layer through the reference's conv_nonsquare. x [H][W][Cin] uint8 -> [OH][OW][Cout] uint8."""
-    ix, iy, ox, oy, ci, co, s = _dims(case_id)
-    h, w, c = x.shape
-    assert c == ci and s == (1 if transposed else 2)
-    assert (ix, iy) == ((2 * w + 4, 2 * h + 4) if transposed else (w + 4, h + 4)), (case_id, ix, iy, x.shape)
-    assert (ox, oy) == ((2 * w, 2 * h) if transposed else ((w + 1) // 2, (h + 1) // 2))
-    img = np.ascontiguousarray(padded_map(x, transposed))
-    W = np.ascontiguousarray(tb_unpack_weights(words, simd, pe, ci, co))
-    b = np.ascontiguousarray(bias, dtype=np.int8)
-    out = np.zeros((ox, oy, co), np.int8)
-    rc = LIB.sicn_refconv_run(case_id, img.ctypes.data, W.ctypes.data, b.ctypes.data, out.ctypes.data)
-    assert rc == 0
-    assert out.min() >= 0
-    return np.ascontiguousarray(out.transpose(1, 0, 2)).view(np.uint8)
+from oracle.ref_conv import dims as _dims, padded_map, ref_layer, tb_unpack_weights  # noqa: E402,F401  (the restated maps / walks live there)
 
 
 def pack_words(W_okkc, simd, pe):

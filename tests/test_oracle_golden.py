@@ -205,3 +205,14 @@ def test_every_oracle_form_matches_reference_compiled_vectors():
             assert np.array_equal(c_oracle.run_layer(d, words, bias, x, form), y), (d, form)
         n += 1
     assert n == 7
+
+
+def test_ref_conv_padded_map_forms_agree():
+    """oracle/ref_conv.py keeps the testbench's zero-stuffed deconv map twice: as the testbench's loops (tb:700-718) and
+    vectorised (what the fixtures script and bench.py's reference leg call)."""
+    from oracle import ref_conv
+    rng = np.random.default_rng(5)
+    for shape in [(1, 1, 3), (7, 5, 3), (4, 9, 16), (6, 6, 1)]:
+        x = rng.integers(0, 256, shape, dtype=np.uint8)
+        for tr in (0, 1):
+            assert np.array_equal(ref_conv.padded_map(x, tr), ref_conv.padded_map_loops(x, tr)), (shape, tr)
