@@ -84,11 +84,17 @@ __global__ __launch_bounds__(256) void k_gdn_selftest(uint32_t n_begin, unsigned
     if (mine) atomicAdd(bad, mine);
 }
 
-template <bool INVERSE>
+// NARROW (the MFMA kernels: C <= 192, so n < 2^29 and r < 2^23): x r is a full-rate 24-bit multiply-add
+template <bool INVERSE, bool NARROW = false>
 __device__ __forceinline__ int gdn_out(int x, uint32_t n, int sh)
 {
     const uint32_t r = INVERSE ? gdn_sqrt8(n) : gdn_rsqrt16(n);
-    int t = (x * (int)r + (1 << (sh - 1))) >> sh;   // |x r| < 2^30; arithmetic shift
+    int t;
+    if (NARROW)   // spelled out: left to itself hipcc folds the add into a quarter-rate v_mad_u64_u32
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t) : "v"(x), "v"(r), "v"(1 << (sh - 1)));
+    else
+        t = x * (int)r + (1 << (sh - 1));
+    t >>= sh;   // |x r| < 2^30; arithmetic shift
     return max(-128, min(127, t));
 }
 
@@ -97,7 +103,7 @@ struct GdnMap {   // byte offset of 16-byte chunk k of position p: (p / P) * pla
 };
 
 template <int NJ, bool INVERSE>
-__global__ __launch_bounds__(256, 2) void k_gdn(uint8_t *__restrict__ data, const int8_t *__restrict__ gamma_img,
+__global__ __launch_bounds__(256, 4) void k_gdn(uint8_t *__restrict__ data, const int8_t *__restrict__ gamma_img,
                                                 const uint32_t *__restrict__ beta, long long image_bytes, uint32_t n_pos,
                                                 GdnMap map, int sh, int blocks_per_image)
 {
@@ -169,7 +175,24 @@ __global__ __launch_bounds__(256, 2) void k_gdn(uint8_t *__restrict__ data, cons
                     lf[J][d] = (int)l;
                 }
             }
-            v4i acc[NT];
+            // Tile j's 4 accumulators per lane are 4 consecutive channels: register r of tile j = channel
+            // 64 (j>>2) + 16 g + 4 (j&3) + r = byte r of dword (j&3) of this lane's chunk J = j>>2.  They are turned into output
+            // bytes right behind the NEXT tile's MFMAs (whose latency the 4 root computations cover) and never kept: the kernel
+            // needs < 128 VGPRs, so four waves share a SIMD — what a VALU-bound loop with MFMA -> VALU wait states wants.
+            v4i y[NJ];
+            auto finish = [&](const v4i &a, int j) {
+                const int J = j >> 2, d = j & 3;
+                uint32_t packed = 0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int x = (int)(int8_t)((uint32_t)xf[J][d] >> (8 * r));
+                    x = max(x, -127);
+                    const int t = gdn_out<INVERSE, true>(x, (uint32_t)a[r], sh);
+                    packed |= ((uint32_t)t & 255u) << (8 * r);
+                }
+                y[J][d] = (int)packed;
+            };
+            v4i a_prev = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < NT; j++) {
                 v4i gf[NJ];
@@ -185,26 +208,13 @@ __global__ __launch_bounds__(256, 2) void k_gdn(uint8_t *__restrict__ data, cons
                 a[3] = (a[3] << 7) + (int)b4.w;
 #pragma unroll
                 for (int J = 0; J < NJ; J++) a = __builtin_amdgcn_mfma_i32_16x16x64_i8(gf[J], lf[J], a, 0, 0, 0);
-                acc[j] = a;
+                if (j > 0) finish(a_prev, j - 1);
+                a_prev = a;
+                __builtin_amdgcn_sched_barrier(0);   // keep the tiles apart: interleaving all of them costs 218 VGPRs
             }
-            // register r of tile j = channel 64 (j>>2) + 16 g + 4 (j&3) + r = byte r of dword (j&3) of this lane's chunk J = j>>2
+            finish(a_prev, NT - 1);
 #pragma unroll
-            for (int J = 0; J < NJ; J++) {
-                v4i y;
-#pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    uint32_t packed = 0;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        int x = (int)(int8_t)((uint32_t)xf[J][d] >> (8 * r));
-                        x = max(x, -127);
-                        const int t = gdn_out<INVERSE>(x, (uint32_t)acc[4 * J + d][r], sh);
-                        packed |= ((uint32_t)t & 255u) << (8 * r);
-                    }
-                    y[d] = (int)packed;
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(y, rs, chunk_off(base, okp, J), 0, 0);
-            }
+            for (int J = 0; J < NJ; J++) __builtin_amdgcn_raw_buffer_store_b128(y[J], rs, chunk_off(base, okp, J), 0, 0);
         }
     }
 }
