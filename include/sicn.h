@@ -98,8 +98,11 @@ typedef struct sicn_options {
     int32_t wave_tile;       /* 0: automatic; 64: always the 64 x 128-per-wave kernels (two waves per SIMD); 128: the  */
                              /*    128 x 128-per-wave kernel (one wave per SIMD) wherever it exists               */
     int32_t prefetch;        /* 0: automatic; 1: never, 2: wherever it exists — the software-pipelined kernels         */
-                             /*    (fragments double-buffered in AGPRs, k_mfma16p.hip)                                 */
-    int32_t reserved[7];
+                             /*    (k_mfma16p.hip); 3: as 2, and the PERSISTENT form (workgroups that walk through many */
+                             /*    tiles, k_conv_pp) wherever that exists, whatever the grid size                      */
+    int32_t persistent_grid; /* 0: two workgroups per CU (512); n: at most n (rounded down to a multiple of 8, >= 8) —  */
+                             /*    tests use it to give every workgroup many tiles of a small input                    */
+    int32_t reserved[6];
 } sicn_options;
 
 typedef struct sicn_weights sicn_weights; /* one layer's weights+bias, resident on the device  */

@@ -411,6 +411,10 @@ static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint
             // (measured, r02: at 192 - 255 tiles the split is a wash or a loss; at <= 72 it takes 20 - 35 % off the layer)
             const long tiles16 = (long)((MW + 15) / 16) * ((MH + TILE_Y - 1) / TILE_Y) * n_images;
             const bool split = tx == 16 && (o.split_n > 1 || (o.split_n == 0 && tiles16 <= 128));
+            // workgroups that walk through many tiles (k_conv_pp): where every one of the 512 residents gets at least 4
+            const long tiles_tx = (long)((MW + tx - 1) / tx) * ((MH + TILE_Y - 1) / TILE_Y) * n_images;
+            if (persistent_supported(g, tx) && (o.prefetch == 3 || (o.prefetch == 0 && tiles_tx >= 4 * 512)))
+                return launch_persistent(g, w, in, out, n_images, stream, in_layout, out_layout, relu, o.persistent_grid);
             return launch_pipelined(g, w, in, out, n_images, stream, in_layout, out_layout, relu, tx, split);
         }
     }

@@ -61,7 +61,7 @@ static int resolve_options(const sicn_options *in, sicn_options *out)
     if (o.strip_chunks < 0 || o.no_phase_layout < 0 || o.no_phase_layout > 2) return SICN_EINVAL;
     if (o.split_n < 0 || o.split_n > 4) return SICN_EINVAL;
     if (o.wave_tile != 0 && o.wave_tile != 64 && o.wave_tile != 128) return SICN_EINVAL;
-    if (o.prefetch < 0 || o.prefetch > 2) return SICN_EINVAL;
+    if (o.prefetch < 0 || o.prefetch > 3 || o.persistent_grid < 0) return SICN_EINVAL;
     *out = o;
     return SICN_OK;
 }
@@ -152,6 +152,7 @@ extern "C" void sicn_weights_free(sicn_weights *w)
     if (w->d_bias) (void)hipFree(w->d_bias);
     if (w->d_w_mfma) (void)hipFree(w->d_w_mfma);
     if (w->d_w_mfma16) (void)hipFree(w->d_w_mfma16);
+    if (w->d_sched) (void)hipFree(w->d_sched);
     if (w->d_w_l0) (void)hipFree(w->d_w_l0);
     if (w->d_w_l7) (void)hipFree(w->d_w_l7);
     delete w;
@@ -214,6 +215,10 @@ extern "C" int sicn_weights_from_finn_tiles(const sicn_layer_desc *d, const void
                 std::vector<int8_t> s16(mfma16_stream_bytes(cin, cout));
                 pack_mfma16_stream(w_okc.data(), cin, cout, d->transposed, s16.data());
                 ok = upload(s16.data(), s16.size(), &w->d_w_mfma16);
+            }
+            if (ok && !d->transposed && cin == 128 && cout == 128) {   // persistent conv kernel: its tile scheduler's counters
+                ok = hipMalloc((void **)&w->d_sched, (size_t)SCHED_SLOTS * SCHED_WORDS * 4) == hipSuccess &&
+                     hipMemset(w->d_sched, 0, (size_t)SCHED_SLOTS * SCHED_WORDS * 4) == hipSuccess;
             }
         }
         if (ok && !d->transposed && cin == 3 && cout % 32 == 0) {

@@ -176,6 +176,39 @@ def test_output_channel_split_in_chain(api, split_n):
     assert _sha(latent[0].cpu().numpy()) == HASHES["layers"]["rng768"][3]
 
 
+PERSISTENT_CASES = [(128, 128, 8, 16, 130, 66, 0), (128, 128, 8, 16, 66, 18, 0), (128, 128, 8, 16, 7, 5, 0), (128, 128, 4, 32, 131, 33, 0),
+                    (128, 128, 8, 16, 200, 90, 0), (128, 128, 8, 16, 64, 16, 0)]
+
+
+@pytest.mark.parametrize("grid", [8, 16, 0])
+@pytest.mark.parametrize("case", PERSISTENT_CASES)
+def test_persistent_conv_matches_oracle(api, case, grid):
+    """k_conv_pp: conv 128 -> 128 by workgroups that walk through MANY tiles (the plane refresh of a tile's last channel group
+    fetches the next tile, the weight ring wraps, the first fragments of a tile are fetched by the last pass of the one
+    before).  Forced (prefetch = 3) with 8 / 16 workgroups so that every one of them gets several tiles of these small
+    inputs — across image boundaries (n = 3), ragged right / bottom tiles, single-tile images — and with the default grid."""
+    rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + grid)
+    d = _mk_desc(*case)
+    W, b, words = _rand_params(rng, d)
+    x = rng.integers(0, 128, (3,) + d.in_shape, dtype=np.uint8)
+    x[0].reshape(-1)[::7] |= 0x80
+    got = _run_layer(api, d, words, b, x, tile_x=32, prefetch=3, persistent_grid=grid)
+    for i in range(3):
+        ref = sicn_ref.conv2d_ref(x[i], W, b)
+        assert np.array_equal(got[i], ref), (i, np.count_nonzero(got[i] != ref))
+
+
+@pytest.mark.parametrize("grid", [8, 40])
+def test_persistent_conv_in_chain(api, grid):
+    xin = _dev(np.stack([_input("rng768"), _input("ones768")]))
+    net = api.EightLayersNet(768, 512, options={"tile_x": 32, "prefetch": 3, "persistent_grid": grid})
+    out, latent = net.forward(xin)
+    torch.cuda.synchronize()
+    for i, name in enumerate(("rng768", "ones768")):
+        assert _sha(out[i].cpu().numpy()) == HASHES["layers"][name][7]
+        assert _sha(latent[i].cpu().numpy()) == HASHES["layers"][name][3]
+
+
 WIDE_CASES = [(128, 128, 8, 16, 66, 18, 0), (128, 128, 8, 16, 7, 5, 0), (128, 128, 8, 16, 1, 1, 0), (128, 128, 4, 32, 131, 33, 0),
               (128, 128, 8, 16, 50, 20, 0), (128, 128, 8, 16, 200, 90, 0), (128, 128, 8, 16, 129, 67, 0)]
 
