@@ -130,7 +130,10 @@ __device__ __forceinline__ void pass_p(v4i (&acc)[Geo<TX>::NC][NT16], const v4i 
 #undef SICN_F
             }
         }
-        if (j == 0) dma();
+#ifndef SICN_X_DMA_AT
+#define SICN_X_DMA_AT 0   // the MFMA group behind which a pass issues its LDS-DMA requests (experiment knob: 2 / 4 / 7 measured within 1 % of 0)
+#endif
+        if (j == (SICN_X_DMA_AT < NT16 ? SICN_X_DMA_AT : NT16 - 1)) dma();
     }
 #if defined(SICN_STAMP) && SICN_STAMP > 1
     if (st) {
