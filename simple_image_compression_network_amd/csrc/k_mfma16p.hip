@@ -244,6 +244,10 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
     const int pos = lane & 15, g = lane >> 4, hi = g >> 1, half = g & 1;
     const TileCoord tc = tile_coord<TX>(tiles_x, n_tiles, n_images);
     if (!tc.valid) return;   // before any LDS-DMA is issued
+#ifdef SICN_STAMP
+    unsigned long long dst[10];   // start, loop start, then (passes done, epilogue done) per phase
+    dst[0] = __builtin_amdgcn_s_memtime();
+#endif
     const int Y0 = tc.Y0, X0 = tc.X0;
     const int in_img_bytes = IH * IW * CIN, out_img_bytes = OH * OW * COUT;
     const uint8_t *in_img = in + (size_t)tc.img * in_img_bytes;
@@ -321,6 +325,9 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
         step += NQ;
     };
     int par = 0;
+#ifdef SICN_STAMP
+    dst[1] = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int ph = 0; ph < 4; ph++) {
         const int py = ph >> 1, px = ph & 1;
@@ -347,10 +354,23 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
                 par ^= 1;
             }
         }
+#ifdef SICN_STAMP
+        dst[2 + 2 * ph] = __builtin_amdgcn_s_memtime();
+#endif
         if (ph == 3) wait_vmcnt<0>();  // the padded tail of the weight prefetch must land before exit
         store_tiles_p<TX, NT16>(acc, out_img, out_img_bytes, om, IW, IH, Y0, X0, w, pos, g, true, py, px, act_floor,
                                 (uint32_t)(split * (COUTW / 32)));
+#ifdef SICN_STAMP
+        dst[3 + 2 * ph] = __builtin_amdgcn_s_memtime();
+#endif
     }
+#ifdef SICN_STAMP
+    if (g_sicn_stamp && lane == 0) {
+        unsigned long long *o = g_sicn_stamp + ((size_t)blockIdx.x * 4 + w) * 12;
+#pragma unroll
+        for (int i = 0; i < 10; i++) o[i] = dst[i];
+    }
+#endif
 }
 
 // =====================================================================================================================
