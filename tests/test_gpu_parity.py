@@ -624,6 +624,39 @@ def test_capture_helper_replays(api):
     assert _sha(lat[0].cpu().numpy()) == HASHES["layers"]["rng768"][3]
 
 
+def test_persistent_conv_graph_replay_and_two_streams(api):
+    """k_conv_pp draws its tiles from ticket counters in a block of device memory that belongs to the layer's weights; every
+    launch takes the next block (16 of them) and zeroes its counters on its own stream.  So (a) a captured forward pass —
+    whose launches are frozen on one block each, with the memset as a graph node — must replay correctly any number of times,
+    and (b) two streams driving ONE net at the same time must not disturb each other's counters."""
+    opts = {"tile_x": 32, "prefetch": 3, "persistent_grid": 16}
+    net = api.EightLayersNet(768, 512, options=opts)
+    x = _dev(np.stack([_input("rng768"), _input("ones768")]))
+    out = torch.empty((2, 512, 768, 3), dtype=torch.uint8, device="cuda")
+    lat = torch.empty((2, 32, 48, 192), dtype=torch.uint8, device="cuda")
+    g = net.capture(x, out, lat)
+    for _ in range(5):
+        out.zero_()
+        g.replay()
+    torch.cuda.synchronize()
+    for i, name in enumerate(("rng768", "ones768")):
+        assert _sha(out[i].cpu().numpy()) == HASHES["layers"][name][7]
+        assert _sha(lat[i].cpu().numpy()) == HASHES["layers"][name][3]
+    # two streams through the SAME device weights (and therefore the same scheduler blocks), each with its own workspace
+    net2 = api.EightLayersNet(768, 512, options=opts, shared_weights=net.weights)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = [torch.empty_like(out) for _ in range(2)]
+    for it in range(12):
+        with torch.cuda.stream(s1):
+            net.forward(x, outs[0], want_latent=False, stream=s1)
+        with torch.cuda.stream(s2):
+            net2.forward(x, outs[1], want_latent=False, stream=s2)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert _sha(o[0].cpu().numpy()) == HASHES["layers"]["rng768"][7]
+        assert _sha(o[1].cpu().numpy()) == HASHES["layers"]["ones768"][7]
+
+
 def test_randomised_sweep_small():
     """tests/fuzz_parity.py (every kernel family + whole chains on random sizes, strip cuts and tile widths) — a
     short seeded run in a child process; the long runs are manual."""
