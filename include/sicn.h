@@ -122,7 +122,11 @@ void sicn_options_init(sicn_options *opt);
  * holding SIMD nibbles (element s in bits [4s,4s+4), weights.hpp:134-139), each word stored in
  * `word_bytes` (1,2,4 or 8) little-endian bytes; `bias` = HOST int8[OFM_CH].  Only desc fields
  * IFM_CH, OFM_CH, SIMD, PE, W_TILES, transposed are used (weights do not depend on image size).
- * Synchronous (uploads to the current device). */
+ * Synchronous (uploads to the current device).
+ * A conv 128 -> 128 handle also owns 16 small blocks of device memory for the tile scheduler of the persistent
+ * kernel: every launch through the handle takes the next block and zeroes its counters on its own stream, so
+ * launches on different streams (or graph nodes of different captures) do not share counters as long as fewer
+ * than 16 launches of the SAME handle are in flight at once. */
 int sicn_weights_from_finn_tiles(const sicn_layer_desc *desc, const void *m_weights, int word_bytes,
                                  const int8_t *bias, sicn_weights **out);
 void sicn_weights_free(sicn_weights *w);
