@@ -415,7 +415,11 @@ static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint
             const long tiles_tx = (long)((MW + tx - 1) / tx) * ((MH + TILE_Y - 1) / TILE_Y) * n_images;
             if (persistent_supported(g, tx) && (o.prefetch == 3 || (o.prefetch == 0 && tiles_tx >= 4 * 512)))
                 return launch_persistent(g, w, in, out, n_images, stream, in_layout, out_layout, relu, o.persistent_grid);
-            return launch_pipelined(g, w, in, out, n_images, stream, in_layout, out_layout, relu, tx, split);
+            // deconv 192 -> 128 on a full grid (>= 1024 tiles): three passes per tap keep the pipelined form from double-buffering its weight
+            // fragments, and there the plain kernel is 7 % faster (layer 4 at 8 x 4K: 0.159 against 0.171 ms); with the
+            // output-channel split (small grids) the pipelined one wins
+            if (!(o.prefetch == 0 && g.transposed && g.CIN == 192 && !split && tiles16 >= 1024))
+                return launch_pipelined(g, w, in, out, n_images, stream, in_layout, out_layout, relu, tx, split);
         }
     }
     // layers 1 / 2 (conv 128 -> 128): the wide form (one wave per SIMD, 128 x 128 tile per wave, k_mfma16w.hip) is bit-exact but
