@@ -5,7 +5,8 @@
 //     12 ds_read_b128 of fragments, NDMA LDS-DMA requests of 1 KiB (global_load_lds), a counted vmcnt wait that leaves two
 //     passes' requests in flight, one workgroup barrier,
 //     32 x 16x16x64  or  16 x 32x32x32 MFMAs.
-// Operands as the net has them (ReLU pixels, sign-extended nibble weights).
+// Operands as the net has them (ReLU pixels, sign-extended nibble weights).  Last three lines: the same passes by ONE 8-wave
+// workgroup per CU (its LDS image is 72 KiB, so two would fit — launch_bounds keeps it at one).
 // build: hipcc --offload-arch=gfx950 -O3 -o mfma_issue_pressure mfma_issue_pressure.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -16,14 +17,14 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
 
-template <int SHAPE, int NDMA>
-__global__ __launch_bounds__(256, 2) void k(const int *__restrict__ src, const unsigned char *__restrict__ stream, int *__restrict__ out, int iters)
+template <int SHAPE, int NDMA, int NTHR>
+__global__ __launch_bounds__(NTHR, 512 / NTHR) void k(const int *__restrict__ src, const unsigned char *__restrict__ stream, int *__restrict__ out, int iters)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 64 KiB operands + 8 KiB DMA landing zone
-    for (int i = threadIdx.x; i < 16384; i += 256) ((int *)smem)[i] = src[i];
+    for (int i = threadIdx.x; i < 16384; i += NTHR) ((int *)smem)[i] = src[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    unsigned char *land = smem + 65536 + w * 2048;
+    unsigned char *land = smem + 65536 + (w & 3) * 2048;
     const unsigned char *gsrc = stream + (size_t)(blockIdx.x & 63) * 65536 + lane * 16;
     v16i acc32[2][4];
     v4i acc16[4][8];
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256, 2) void k(const int *__restrict__ src, const u
     for (int it = 0; it < iters; it++) {
         // fragments of this pass (12 reads)
         v4i pf[4], wf[8];
-        const unsigned char *base = smem + ((it * 8192 + w * 1024) & 0x7FFF);
+        const unsigned char *base = smem + ((it * 8192 + (w & 3) * 1024) & 0x7FFF);
 #pragma unroll
         for (int i = 0; i < 4; i++) pf[i] = *(const v4i *)(base + ((i * 1024 + lane * 16) & 0x3FFF));
 #pragma unroll
@@ -61,27 +62,27 @@ __global__ __launch_bounds__(256, 2) void k(const int *__restrict__ src, const u
     int s = 0;
     if (SHAPE == 0) { for (int i = 0; i < 2; i++) for (int j = 0; j < 4; j++) for (int r = 0; r < 16; r++) s += acc32[i][j][r]; }
     else { for (int i = 0; i < 4; i++) for (int j = 0; j < 8; j++) for (int r = 0; r < 4; r++) s += acc16[i][j][r]; }
-    out[blockIdx.x * 256 + threadIdx.x] = s + land[lane];
+    out[blockIdx.x * NTHR + threadIdx.x] = s + land[lane];
 }
 
-template <int SHAPE, int NDMA>
+template <int SHAPE, int NDMA, int NTHR = 256>
 static void run(const char *name, const int *src, const unsigned char *stream, int *out, int round)
 {
-    const int iters = 2000, blocks = 2048;
+    const int iters = 2000, blocks = 2048 * 256 / NTHR;
     const size_t lds = 65536 + 8192;
-    hipFuncSetAttribute((const void *)k<SHAPE, NDMA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void *)k<SHAPE, NDMA, NTHR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t a, b;
     hipEventCreate(&a);
     hipEventCreate(&b);
-    for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL((k<SHAPE, NDMA>), dim3(blocks), dim3(256), lds, 0, src, stream, out, iters);
+    for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL((k<SHAPE, NDMA, NTHR>), dim3(blocks), dim3(NTHR), lds, 0, src, stream, out, iters);
     hipEventRecord(a);
-    for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL((k<SHAPE, NDMA>), dim3(blocks), dim3(256), lds, 0, src, stream, out, iters);
+    for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL((k<SHAPE, NDMA, NTHR>), dim3(blocks), dim3(NTHR), lds, 0, src, stream, out, iters);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms;
     hipEventElapsedTime(&ms, a, b);
     ms /= 3;
-    const double ops = 2.0 * blocks * 4 * (double)iters * 64 * 128 * 64;
+    const double ops = 2.0 * blocks * (NTHR / 64) * (double)iters * 64 * 128 * 64;
     printf("round %d %-9s %d requests per pass: %.3f ms  %.2f POP/s\n", round, name, NDMA, ms, ops / ms / 1e12);
     fflush(stdout);
 }
@@ -106,6 +107,11 @@ int main()
         run<0, 2>("32x32x32", src, stream, out, round);
         run<1, 3>("16x16x64", src, stream, out, round);
         run<0, 3>("32x32x32", src, stream, out, round);
+        // ONE workgroup of 8 waves per CU instead of two of 4 (both waves of a SIMD behind the same barrier; a shared weight ring
+        // and a taller tile would halve the requests per wave and pass)
+        run<1, 1, 512>("8w 16x16", src, stream, out, round);
+        run<1, 2, 512>("8w 16x16", src, stream, out, round);
+        run<1, 3, 512>("8w 16x16", src, stream, out, round);
     }
     return 0;
 }
