@@ -45,6 +45,10 @@ for case in range(args.cases):
         env["tile_x"] = int(rng.choice([16, 32]))
     if rng.random() < 0.3:
         env["split_n"] = int(rng.choice([1, 2, 4]))
+    if rng.random() < 0.4:       # the persistent conv kernel (only conv 128 -> 128 at 8 x 32 tiles takes it; others ignore the request)
+        env["prefetch"] = 3
+        env["tile_x"] = 32
+        env["persistent_grid"] = int(rng.choice([8, 16, 64, 0]))
     W = rng.integers(-8, 8, (cout, 5, 5, cin)).astype(np.int8)
     b = rng.integers(-128, 128, cout).astype(np.int8)
     words = sicn_ref.pack_finn_tiles(W, simd, pe)
@@ -76,6 +80,10 @@ for case in range(args.chains):
         env["strip_chunks"] = int(rng.integers(1, 6))
     if rng.random() < 0.3:
         env["split_n"] = int(rng.choice([1, 2, 4]))
+    if rng.random() < 0.4:
+        env["prefetch"] = 3
+        env["tile_x"] = 32
+        env["persistent_grid"] = int(rng.choice([8, 16, 64, 0]))
     w, h, n = int(rng.integers(1, 26)) * 16, int(rng.integers(1, 20)) * 16, int(rng.integers(1, 3))
     descs = eight_layer_descs(w, h)
     params_np, params = [], []
