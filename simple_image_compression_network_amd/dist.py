@@ -2,10 +2,14 @@
 
 Images are independent (conv_nonsquare_top.cpp:295-357 keeps no cross-image state), so the only
 multi-GPU parallelism of this path is along the batch: image i belongs to rank i mod world.  There
-is NO data-path collective.  The collectives here are bookkeeping (per-image checksums / timing) and
+is NO data-path collective on that axis.  The collectives here are bookkeeping (per-image checksums / timing) and
 run over whatever backend the process group was created with: "nccl" (= RCCL over xGMI) on GPUs,
 "gloo" in the CPU tests.  Weights (1.44 MB packed) are read by rank 0 and replicated with one
 broadcast at start-up (`broadcast_params`), so every rank provably runs the same tables.
+
+Optional second axis ("single-image spatial split"): ONE large image over the ranks by horizontal bands with a
+recomputed halo (`band_plan`, `forward_banded`) — the only place on this path where tensors cross GPUs: the bands of the
+reconstruction (and of the latent) are all-gathered.
 """
 from __future__ import annotations
 
@@ -14,7 +18,7 @@ from typing import Callable, Dict, List, Sequence
 
 import numpy as np
 
-__all__ = ["shard_indices", "checksum", "run_sharded", "broadcast_params"]
+__all__ = ["shard_indices", "checksum", "run_sharded", "broadcast_params", "band_plan", "forward_banded", "BAND_HALO"]
 
 
 def shard_indices(n_images: int, rank: int, world: int) -> List[int]:
@@ -94,3 +98,79 @@ def run_sharded(n_images: int, make_image: Callable[[int], np.ndarray],
     if sorted(out) != list(range(n_images)):
         raise RuntimeError("sharding lost or duplicated images")
     return out
+
+
+# ---- one image over several GPUs: horizontal bands with a recomputed halo ------------------------------------------------
+# Output row y of eight_layers_net depends on latent rows [y/16 - 2, y/16 + 2] (four deconv522 layers, each reaching one
+# input row to either side: 1 + 1/2 + 1/4 + 1/8 < 2 latent rows) and latent row r on input rows [16 r - 30, 16 r + 30] (four
+# conv2d layers: 2 + 4 + 8 + 16), so rows [a, b) of the reconstruction are a function of input rows [a - 62, b + 62) only.
+# A band that starts and ends on multiples of 16 keeps every layer's stride-2 grid aligned with the whole image's, and with 64
+# rows of halo the zero padding the band sees at its cut edges (instead of the neighbouring rows) cannot reach the rows it keeps.
+BAND_HALO = 64
+
+
+def band_plan(height: int, n_bands: int, halo: int = BAND_HALO, align: int = 16):
+    """Cut `height` input rows into `n_bands` bands: [(in_begin, in_end, keep_begin, keep_end)], all in input rows; keep ranges
+    are multiples of `align` (but for the image's last row), partition [0, height) and are non-empty for every band; a band
+    reads [in_begin, in_end) = its keep range widened by `halo` and clipped to the image."""
+    if height <= 0 or n_bands <= 0 or halo % align or halo < 62:
+        raise ValueError("need height, n_bands > 0 and a halo that is a multiple of the alignment and >= 62 rows")
+    units = (height + align - 1) // align                  # latent rows
+    if n_bands > units:
+        raise ValueError(f"{n_bands} bands for {units} rows of {align}")
+    plan = []
+    for b in range(n_bands):
+        k0 = align * (units * b // n_bands)
+        k1 = min(height, align * (units * (b + 1) // n_bands))
+        plan.append((max(0, k0 - halo), min(height, k1 + halo), k0, k1))
+    return plan
+
+
+def forward_banded(compute: Callable[[np.ndarray], Sequence[np.ndarray]], image: np.ndarray, n_bands: int = 0, group=None):
+    """`eight_layers_net` of ONE image [H][W][3] computed band by band: `compute` maps a band [h][W][3] to (reconstruction
+    [16 ceil(h/16)][W'][3], latent [ceil(h/16)][..][192]) — the HIP path in production, the oracle in the CPU tests.
+    With an initialised process group rank r computes band r (n_bands = world size) and the kept rows are all-gathered
+    (RCCL over xGMI with backend nccl); without one, the bands are computed one after the other (n_bands as given).
+    Returns (reconstruction, latent) of the whole image on every rank — byte-identical to one call on the whole image."""
+    import torch
+    import torch.distributed as dist
+
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if distributed:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        n_bands = world
+    else:
+        rank, world = 0, 1
+        if n_bands <= 0:
+            raise ValueError("n_bands must be given without a process group")
+    H = image.shape[0]
+    plan = band_plan(H, n_bands)
+    out_rows = 16 * ((H + 15) // 16)                        # the net's output height (conv rounds up, deconv doubles)
+
+    def one(b):
+        i0, i1, k0, k1 = plan[b]
+        recon, latent = compute(np.ascontiguousarray(image[i0:i1]))
+        last = b == n_bands - 1
+        r1 = (out_rows if last else k1) - i0                 # the last band also owns the rows the rounding adds
+        return (np.ascontiguousarray(recon[k0 - i0:r1]), np.ascontiguousarray(latent[(k0 - i0) // 16:(r1 + 15) // 16]))
+
+    if not distributed:
+        parts = [one(b) for b in range(n_bands)]
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+    mine = one(rank)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    outs = []
+    for part, full_rows in ((mine[0], out_rows), (mine[1], (H + 15) // 16)):
+        # bands differ in height by at most one row of 16: pad to the tallest, gather, cut
+        rows = [((out_rows if b == n_bands - 1 else plan[b][3]) - plan[b][2]) for b in range(n_bands)]
+        if full_rows != out_rows:
+            rows = [(r + 15) // 16 for r in rows]
+        tallest = max(rows)
+        buf = np.zeros((tallest,) + part.shape[1:], np.uint8)
+        buf[:part.shape[0]] = part
+        mine_t = torch.from_numpy(buf).to(dev)
+        gathered = [torch.empty_like(mine_t) for _ in range(world)]
+        dist.all_gather(gathered, mine_t, group=group)
+        outs.append(np.concatenate([g.cpu().numpy()[:rows[b]] for b, g in enumerate(gathered)]))
+    return outs[0], outs[1]

@@ -79,3 +79,82 @@ def test_two_ranks_gloo_agree_with_single_process():
         assert p.exitcode == 0
     single = run_sharded(N, _make_image, _oracle_compute)
     assert results[0] == results[1] == single
+
+
+# ---- one image over several ranks: bands with a recomputed halo --------------------------------------------------------------
+from simple_image_compression_network_amd.dist import BAND_HALO, band_plan, forward_banded  # noqa: E402
+
+BW, BH = 32, 304        # 19 latent rows: bands of uneven height, a last band that is not a multiple of 16 rows high
+
+
+def _oracle_band(band):
+    from oracle import c_oracle
+    from simple_image_compression_network_amd.config import eight_layer_descs
+    z = np.load(ROOT / "tests" / "golden" / "param_weights.npz")
+    outs = c_oracle.run_net(eight_layer_descs(band.shape[1], band.shape[0]), [z[f"w{n}_words"] for n in range(8)],
+                            [z[f"b{n}"] for n in range(8)], band, "direct", threads=2)
+    return outs[7], outs[3]
+
+
+def test_band_plan_partitions_rows():
+    for height in (16, 17, 304, 1080, 2160):
+        units = (height + 15) // 16
+        for n in (1, 2, 3, 8):
+            if n > units:
+                with pytest.raises(ValueError):
+                    band_plan(height, n)
+                continue
+            plan = band_plan(height, n)
+            assert plan[0][2] == 0 and plan[-1][3] == height
+            for (i0, i1, k0, k1), nxt in zip(plan, plan[1:] + [None]):
+                assert 0 <= i0 <= k0 < k1 <= i1 <= height and k0 % 16 == 0 and i0 % 16 == 0
+                assert k0 - i0 in (0, BAND_HALO) or i0 == 0
+                if nxt is not None:
+                    assert k1 == nxt[2] and k1 % 16 == 0
+    with pytest.raises(ValueError):
+        band_plan(304, 2, halo=48)       # fewer than the 62 rows the receptive field needs
+
+
+def test_banded_forward_equals_whole_image():
+    img = np.random.default_rng(11).integers(0, 256, (BH, BW, 3), dtype=np.uint8)
+    whole_recon, whole_latent = _oracle_band(img)
+    for n in (2, 3):
+        recon, latent = forward_banded(_oracle_band, img, n_bands=n)
+        assert np.array_equal(recon, whole_recon) and np.array_equal(latent, whole_latent), n
+    odd = img[:297]                      # 297 rows: the net rounds up to 304 output rows; the last band owns them
+    whole_recon, whole_latent = _oracle_band(odd)
+    recon, latent = forward_banded(_oracle_band, odd, n_bands=2)
+    assert recon.shape == whole_recon.shape and np.array_equal(recon, whole_recon) and np.array_equal(latent, whole_latent)
+
+
+def _band_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        img = np.random.default_rng(11).integers(0, 256, (BH, BW, 3), dtype=np.uint8)
+        recon, latent = forward_banded(_oracle_band, img)
+        q.put((rank, checksum(recon), checksum(latent), recon.shape, latent.shape))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_banded_image():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_band_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    img = np.random.default_rng(11).integers(0, 256, (BH, BW, 3), dtype=np.uint8)
+    recon, latent = _oracle_band(img)
+    for _, cr, cl, sr, sl in results:
+        assert (cr, cl, sr, sl) == (checksum(recon), checksum(latent), recon.shape, latent.shape)

@@ -657,6 +657,30 @@ def test_persistent_conv_graph_replay_and_two_streams(api):
         assert _sha(o[1].cpu().numpy()) == HASHES["layers"]["ones768"][7]
 
 
+def test_banded_single_image_equals_whole_image(api):
+    """dist.forward_banded (the optional spatial split): one image cut into horizontal bands with 64 rows of
+    recomputed halo, every band through the HIP path on its own, the kept rows put together — byte-identical to one call on
+    the whole image (1080 rows: not a multiple of 16; 3 and 5 bands: uneven heights)."""
+    from simple_image_compression_network_amd.dist import forward_banded
+    w, h = 256, 1080
+    img = np.random.default_rng(21).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    nets = {}
+
+    def compute(band):
+        hb = band.shape[0]
+        if hb not in nets:
+            nets[hb] = api.EightLayersNet(w, hb)
+        out, lat = nets[hb].forward(torch.from_numpy(band[None]).cuda())
+        torch.cuda.synchronize()
+        return out[0].cpu().numpy(), lat[0].cpu().numpy()
+
+    whole_out, whole_lat = compute(img)
+    for n in (3, 5):
+        out, lat = forward_banded(compute, img, n_bands=n)
+        assert out.shape == whole_out.shape and np.array_equal(out, whole_out), n
+        assert np.array_equal(lat, whole_lat), n
+
+
 def test_randomised_sweep_small():
     """tests/fuzz_parity.py (every kernel family + whole chains on random sizes, strip cuts and tile widths) — a
     short seeded run in a child process; the long runs are manual."""
