@@ -14,6 +14,9 @@
 //     second set; only the pixel fragments (used by every weight tile of the pass) are double-buffered (+16 VGPRs);
 //   * the barrier that ends pass k therefore publishes the weight tiles of pass k+2: the ring runs 4 passes ahead (PFP = 8);
 //   * a pass's LDS-DMA requests are issued behind its first MFMA group: the MFMA pipe restarts right after the barrier.
+// Also in this file: the output-channel split of the 8 x 16 kernels for grids smaller than the chip (NT16 < NTF, launch_p),
+// k_conv_pp — conv 128 -> 128 by PERSISTENT workgroups that walk through many tiles, dealt by a per-XCD ticket counter (its
+// header comment has the why and the how) — and, under -DSICN_STAMP only, in-kernel s_memtime stamps for tools/*_stamps.py.
 // Hazards hipcc cannot see inside asm are covered by hand: s_nop between a VALU write and an asm MFMA that reads it as C, an
 // asm statement that keeps the C operand's registers live (and waits) behind the MFMAs that read them, s_nop before the
 // epilogue reads the accumulators.
