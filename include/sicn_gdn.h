@@ -54,6 +54,8 @@ int sicn_net_create_gdn(const sicn_layer_desc *descs, sicn_weights *const *weigh
  * the device code gets from a float estimate and an integer fix-up — against integer bisection, on the device, for every
  * n in [n_begin, n_begin + count).  Synchronous.  Returns the number of n whose root differs (0 = exact), < 0 on error. */
 long long sicn_gdn_selftest_roots(int inverse, uint32_t n_begin, unsigned long long count);
+/* The same for the two-test form of floor(2^8 sqrt(n)) that the MFMA kernels (C <= 192: n < 2^29) use; n_begin + count <= 2^29. */
+long long sicn_gdn_selftest_roots_narrow(uint32_t n_begin, unsigned long long count);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,17 @@ __device__ __forceinline__ uint32_t gdn_sqrt8(uint32_t n)
     return r0 - 2 + (1 - r2 <= d ? 1u : 0u) + (0 <= d ? 1u : 0u) + (r2 + 1 <= d ? 1u : 0u) + (2 * r2 + 4 <= d ? 1u : 0u);
 }
 
+// The same root for n < 2^29 (the MFMA kernels: C <= 192), where the estimate is within 0.89 of the true value (cvt 2^-25 +
+// v_sqrt_f32 2^-23 relative, of at most 5.93e6): with q = floor(t~ + 0.95) the floor is q - 2, q - 1 or q — TWO tests instead of
+// four: r = q - 2 + [(q - 1)^2 <= N] + [q^2 <= N], i.e. with d = N - q^2: [1 - 2 q <= d] + [0 <= d].
+__device__ __forceinline__ uint32_t gdn_sqrt8_narrow(uint32_t n)
+{
+    uint32_t q = (uint32_t)(256.0f * __fsqrt_rn((float)n) + 0.95f);
+    q = max(q, 2u);
+    const int d = (int)((n << 16) - __umul24(q, q));
+    return q - 2 + (1 - (int)(2u * q) <= d ? 1u : 0u) + (0 <= d ? 1u : 0u);
+}
+
 // exact references for the self-test: integer bisection, as in oracle/sicn_gdn_oracle.c
 __device__ uint32_t gdn_rsqrt16_slow(uint32_t n)
 {
@@ -78,7 +89,8 @@ __global__ __launch_bounds__(256) void k_gdn_selftest(uint32_t n_begin, unsigned
     for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * 256) {
         const uint32_t n = n_begin + (uint32_t)i;
         if (!inverse && n == 0) continue;   // GDN: n >= 1 (beta >= 1)
-        const uint32_t fast = inverse ? gdn_sqrt8(n) : gdn_rsqrt16(n), slow = inverse ? gdn_sqrt8_slow(n) : gdn_rsqrt16_slow(n);
+        const uint32_t fast = inverse == 2 ? gdn_sqrt8_narrow(n) : inverse ? gdn_sqrt8(n) : gdn_rsqrt16(n);
+        const uint32_t slow = inverse ? gdn_sqrt8_slow(n) : gdn_rsqrt16_slow(n);
         mine += fast != slow;
     }
     if (mine) atomicAdd(bad, mine);
@@ -88,7 +100,7 @@ __global__ __launch_bounds__(256) void k_gdn_selftest(uint32_t n_begin, unsigned
 template <bool INVERSE, bool NARROW = false>
 __device__ __forceinline__ int gdn_out(int x, uint32_t n, int sh)
 {
-    const uint32_t r = INVERSE ? gdn_sqrt8(n) : gdn_rsqrt16(n);
+    const uint32_t r = INVERSE ? (NARROW ? gdn_sqrt8_narrow(n) : gdn_sqrt8(n)) : gdn_rsqrt16(n);
     int t;
     if (NARROW)   // spelled out: left to itself hipcc folds the add into a quarter-rate v_mad_u64_u32
         asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t) : "v"(x), "v"(r), "v"(1 << (sh - 1)));
@@ -319,3 +331,12 @@ hipError_t gdn_selftest_roots(int inverse, uint32_t n_begin, unsigned long long 
 }
 
 }  // namespace sicn
+
+// Test hook for the root the MFMA kernels use on the IGDN side (gdn_sqrt8_narrow, n < 2^29): as sicn_gdn_selftest_roots.
+extern "C" long long sicn_gdn_selftest_roots_narrow(uint32_t n_begin, unsigned long long count)
+{
+    if ((unsigned long long)n_begin + count > (1ull << 29)) return -22;
+    unsigned long long bad = 0;
+    if (sicn::gdn_selftest_roots(2, n_begin, count, &bad) != hipSuccess) return -19;
+    return (long long)bad;
+}

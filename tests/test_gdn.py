@@ -165,6 +165,10 @@ def test_gpu_gdn_roots_exact_for_every_n(inverse):
     for begin in range(0, 1 << 31, step):
         assert L.sicn_gdn_selftest_roots(inverse, begin, step) == 0, (inverse, begin)
     assert L.sicn_gdn_selftest_roots(inverse, 0, (1 << 31) + 1) == -22
+    if inverse:      # the two-test form the MFMA kernels use below 2^29
+        for begin in range(0, 1 << 29, step):
+            assert L.sicn_gdn_selftest_roots_narrow(begin, min(step, (1 << 29) - begin)) == 0, begin
+        assert L.sicn_gdn_selftest_roots_narrow(0, (1 << 29) + 1) == -22
 
 
 # every kernel family that can carry a GDN: l0_rgb, mfma_conv (128 and 192 out), mfma_deconv, generic (incl. the RGB-out
