@@ -32,10 +32,10 @@ namespace sicn {
 __device__ __forceinline__ uint32_t gdn_rsqrt16(uint32_t n)
 {
     uint32_t q = (uint32_t)(65536.0f * __frsqrt_rn((float)n) + 0.05f);
-    q = max(1u, min(q, 65535u));
+    q = max(1u, min(q, 65536u));
+    // q = 65536 only for n = 1 (r = 2^16 exactly): its 24-bit square wraps to 0, the product is 0 and the test passes — as it must
     const unsigned long long prod = (unsigned long long)(uint32_t)__umul24(q, q) * n;   // one v_mad_u64_u32 (__umul24 returns int)
-    const uint32_t r = q - (prod > (1ull << 32) ? 1u : 0u);
-    return n <= 1 ? 65536u : r;
+    return q - (prod > (1ull << 32) ? 1u : 0u);
 }
 
 // r = max{ r : r^2 <= n 2^16 } = floor(2^8 sqrt(n)), n < 2^31 (r < 2^23.6).  The float estimate r0 is within 2 of it (relative
