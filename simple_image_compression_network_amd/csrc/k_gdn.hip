@@ -31,8 +31,8 @@ namespace sicn {
 // 24-bit multiply; the 64-bit product costs the two slow ones.
 __device__ __forceinline__ uint32_t gdn_rsqrt16(uint32_t n)
 {
-    uint32_t q = (uint32_t)(65536.0f * __frsqrt_rn((float)n) + 0.05f);
-    q = max(1u, min(q, 65536u));
+    // 1 <= n < 2^31 puts t~ + 0.05 into [1.46, 65536.06], so q needs no clamp (n = 0 is excluded by beta >= 1)
+    const uint32_t q = (uint32_t)(65536.0f * __frsqrt_rn((float)n) + 0.05f);
     // q = 65536 only for n = 1 (r = 2^16 exactly): its 24-bit square wraps to 0, the product is 0 and the test passes — as it must
     const unsigned long long prod = (unsigned long long)(uint32_t)__umul24(q, q) * n;   // one v_mad_u64_u32 (__umul24 returns int)
     return q - (prod > (1ull << 32) ? 1u : 0u);
