@@ -60,8 +60,8 @@ def kernel_source_fingerprint() -> str:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)   # 40 x 4.2 ms: long enough for the chip to settle at the clock it holds
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--images-per-gpu", type=int, default=8)
