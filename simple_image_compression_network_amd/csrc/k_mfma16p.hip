@@ -815,10 +815,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_pp(const uint8_t *__restrict__ 
                 // spills live in VGPR lanes — and hipcc's hazard recogniser does not look inside asm: without the wait states the
                 // atomic went to a stale address and faulted.)  Spelled out in asm: hipcc would put a vmcnt(0) right behind the
                 // atomic; here the wait sits behind nothing younger than the requests of passes 48 / 49 (a pass or more old),
-                // and the output stores are issued after it, so it never waits for a store.
+                // and the output stores are issued after it, so it never waits for a store.  sc1: the counter is coherent across
+                // the XCDs' L2s, so correctness does not rest on workgroup l really running on XCD l % 8 (only locality does).
                 if (lane_e == 0) {
                     uint32_t t = 1, zero = 0;
-                    asm volatile("s_nop 7\n\tglobal_atomic_add %0, %1, %0, %2 sc0\n\ts_waitcnt vmcnt(0)" : "+v"(t) : "v"(zero), "s"(sched + xcd) : "memory");
+                    asm volatile("s_nop 7\n\tglobal_atomic_add %0, %1, %0, %2 sc0 sc1\n\ts_waitcnt vmcnt(0)" : "+v"(t) : "v"(zero), "s"(sched + xcd) : "memory");
                     __hip_atomic_store(&sched[N_XCD + blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
