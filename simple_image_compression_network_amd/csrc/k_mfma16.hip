@@ -398,6 +398,13 @@ static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint
                            hipStream_t stream, int in_layout, int out_layout, const sicn_options &o, bool relu)
 {
     const int MW = DECONV ? g.IW : g.OW, MH = DECONV ? g.IH : g.OH;
+    // the wide persistent form (k_mfma16x.hip: one workgroup of 4 waves per CU, 16 x 32 positions, 128 x 128 outputs per wave):
+    // where every CU gets at least WIDE_MIN_TILES tiles; sicn_options.wave_tile = 128 forces it, 64 forbids it
+    if (wide_supported(g) && o.tile_x != 16) {
+        const long tiles_w = (long)((MW + 31) / 32) * ((MH + 15) / 16) * n_images;
+        if (o.wave_tile == 128 || (o.wave_tile == 0 && o.prefetch == 0 && tiles_w >= 256L * WIDE_MIN_TILES))
+            return launch_wide(g, w, in, out, n_images, stream, in_layout, out_layout, relu, o.persistent_grid);
+    }
     const long tiles32 = (long)((MW + 31) / 32) * ((MH + TILE_Y - 1) / TILE_Y) * n_images;
     bool narrow = minw16(NQ, NT16, 32) == 1 || tiles32 < 2 * 256;
     if (o.tile_x == 16) narrow = true;
@@ -405,8 +412,7 @@ static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint
     // the software-pipelined form of the same kernels (k_mfma16p.hip) is the default wherever it exists
     {
         const int tx = narrow ? 16 : 32;
-        const bool wide_asked = !DECONV && NQ == 4 && NT16 == 8 && !narrow && o.wave_tile == 128;
-        if (o.prefetch != 1 && !wide_asked && pipelined_supported(g, tx)) {
+        if (o.prefetch != 1 && pipelined_supported(g, tx)) {
             // grids that leave half of the CUs without a workgroup: split the output channels over 2 / 3 workgroups
             // (measured, r02: at 192 - 255 tiles the split is a wash or a loss; at <= 72 it takes 20 - 35 % off the layer)
             const long tiles16 = (long)((MW + 15) / 16) * ((MH + TILE_Y - 1) / TILE_Y) * n_images;
@@ -422,11 +428,6 @@ static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint
                 return launch_pipelined(g, w, in, out, n_images, stream, in_layout, out_layout, relu, tx, split);
         }
     }
-    // layers 1 / 2 (conv 128 -> 128): the wide form (one wave per SIMD, 128 x 128 tile per wave, k_mfma16w.hip) is bit-exact but
-    // measured 8 % SLOWER than this file's kernels on 8 x 4K (its per-tile prologue / epilogue has no partner wave to hide
-    // behind): opt-in only (sicn_options.wave_tile = 128)
-    if constexpr (!DECONV && NQ == 4 && NT16 == 8)
-        if (!narrow && o.wave_tile == 128) return launch_conv128w(g, w, in, out, n_images, stream, in_layout, out_layout, relu);
     return narrow ? launch16_tx<NQ, NT16, DECONV, 16>(g, w, in, out, n_images, stream, in_layout, out_layout, relu)
                   : launch16_tx<NQ, NT16, DECONV, 32>(g, w, in, out, n_images, stream, in_layout, out_layout, relu);
 }

@@ -72,9 +72,12 @@ hipError_t launch_mfma(const LayerGeom &g, const sicn_weights &w, const uint8_t 
                        int n_images, hipStream_t stream, int in_layout, int out_layout);
 hipError_t launch_mfma16(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
                          int n_images, hipStream_t stream, int in_layout, int out_layout, const sicn_options &o, bool relu = true);
-// k_mfma16w.hip: conv 128 -> 128 with a 128 x 128 output tile per wave (accumulators in AGPRs, one wave per SIMD)
-hipError_t launch_conv128w(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
-                           hipStream_t stream, int in_layout, int out_layout, bool relu);
+// k_mfma16x.hip: the wide persistent form — one workgroup of 4 waves per CU walks through 16 x 32-position tiles, 128 x 128 outputs
+// per wave (accumulators in AGPRs, one wave per SIMD); grid_cap > 0 limits the number of workgroups (tests)
+constexpr int WIDE_MIN_TILES = 4;   // automatic from this many tiles per CU on
+bool wide_supported(const LayerGeom &g);
+hipError_t launch_wide(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images, hipStream_t stream,
+                       int in_layout, int out_layout, bool relu, int grid_cap);
 // k_mfma16p.hip: the software-pipelined conv / deconv kernels (tile_x = 16 | 32)
 bool pipelined_supported(const LayerGeom &g, int tile_x);
 bool persistent_supported(const LayerGeom &g, int tile_x);

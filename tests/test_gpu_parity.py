@@ -210,29 +210,31 @@ def test_persistent_conv_in_chain(api, grid):
 
 
 WIDE_CASES = [(128, 128, 8, 16, 66, 18, 0), (128, 128, 8, 16, 7, 5, 0), (128, 128, 8, 16, 1, 1, 0), (128, 128, 4, 32, 131, 33, 0),
-              (128, 128, 8, 16, 50, 20, 0), (128, 128, 8, 16, 200, 90, 0), (128, 128, 8, 16, 129, 67, 0)]
+              (128, 128, 8, 16, 50, 20, 0), (128, 128, 8, 16, 200, 90, 0), (128, 128, 8, 16, 129, 67, 0), (128, 128, 8, 16, 300, 260, 0)]
 
 
-@pytest.mark.parametrize("wave_tile", [64, 128])
+@pytest.mark.parametrize("wave_tile,grid", [(64, 0), (128, 0), (128, 8), (128, 16)])
 @pytest.mark.parametrize("case", WIDE_CASES)
-def test_wide_wave_tile_conv_matches_oracle(api, case, wave_tile):
-    """conv 128 -> 128 exists in two forms: 64 x 128 outputs per wave at two waves per SIMD (k_mfma16.hip) and 128 x 128 per
-    wave with AGPR-pinned accumulators at one wave per SIMD (k_mfma16w.hip, the default on full-size grids). Force each
-    (tile_x = 32 so that small shapes reach them) on odd sizes, single pixels, several tiles, pixels with the high bit."""
-    rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + wave_tile)
+def test_wide_wave_tile_conv_matches_oracle(api, case, wave_tile, grid):
+    """conv 128 -> 128 exists in two forms: 64 x 128 outputs per wave at two waves per SIMD (k_mfma16.hip / k_mfma16p.hip) and
+    128 x 128 per wave with AGPR-pinned accumulators at one wave per SIMD, by PERSISTENT workgroups that walk through 16 x 32
+    tiles (k_mfma16x.hip, the default on full-size grids).  Force each on odd sizes, single pixels, several tiles, pixels with
+    the high bit; the persistent form also with 8 / 16 workgroups, so that every one of them walks through several tiles —
+    across image boundaries (n = 3), ragged right / bottom tiles, single-tile images."""
+    rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + wave_tile + grid)
     d = _mk_desc(*case)
     W, b, words = _rand_params(rng, d)
     x = rng.integers(0, 128, (3,) + d.in_shape, dtype=np.uint8)
     x[0].reshape(-1)[::7] |= 0x80
-    got = _run_layer(api, d, words, b, x, tile_x=32, wave_tile=wave_tile, prefetch=1)
+    got = _run_layer(api, d, words, b, x, tile_x=32, wave_tile=wave_tile, prefetch=1, persistent_grid=grid)
     for i in range(3):
         assert np.array_equal(got[i], sicn_ref.conv2d_ref(x[i], W, b)), (i, np.count_nonzero(got[i] != sicn_ref.conv2d_ref(x[i], W, b)))
 
 
-@pytest.mark.parametrize("wave_tile", [64, 128])
-def test_wide_wave_tile_in_chain(api, wave_tile):
+@pytest.mark.parametrize("wave_tile,grid", [(64, 0), (128, 0), (128, 8)])
+def test_wide_wave_tile_in_chain(api, wave_tile, grid):
     xin = _dev(_input("rng768")[None])
-    net = api.EightLayersNet(768, 512, options={"tile_x": 32, "wave_tile": wave_tile, "prefetch": 1})
+    net = api.EightLayersNet(768, 512, options={"tile_x": 32, "wave_tile": wave_tile, "prefetch": 1, "persistent_grid": grid})
     out, latent = net.forward(xin)
     torch.cuda.synchronize()
     assert _sha(out[0].cpu().numpy()) == HASHES["layers"]["rng768"][7]
