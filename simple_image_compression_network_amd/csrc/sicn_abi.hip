@@ -152,6 +152,7 @@ extern "C" void sicn_weights_free(sicn_weights *w)
     if (w->d_bias) (void)hipFree(w->d_bias);
     if (w->d_w_mfma) (void)hipFree(w->d_w_mfma);
     if (w->d_w_mfma16) (void)hipFree(w->d_w_mfma16);
+    if (w->d_w_mfma16x) (void)hipFree(w->d_w_mfma16x);
     if (w->d_sched) (void)hipFree(w->d_sched);
     if (w->d_w_l0) (void)hipFree(w->d_w_l0);
     if (w->d_w_l7) (void)hipFree(w->d_w_l7);
@@ -215,6 +216,11 @@ extern "C" int sicn_weights_from_finn_tiles(const sicn_layer_desc *d, const void
                 std::vector<int8_t> s16(mfma16_stream_bytes(cin, cout));
                 pack_mfma16_stream(w_okc.data(), cin, cout, d->transposed, s16.data());
                 ok = upload(s16.data(), s16.size(), &w->d_w_mfma16);
+            }
+            if (ok && d->transposed && mfma16x_deconv_stream_bytes(cin, cout)) {   // the wide persistent deconv walks the taps in its own order
+                std::vector<int8_t> sx(mfma16x_deconv_stream_bytes(cin, cout));
+                pack_mfma16x_deconv_stream(w_okc.data(), cin, cout, sx.data());
+                ok = upload(sx.data(), sx.size(), &w->d_w_mfma16x);
             }
             if (ok && !d->transposed && cin == 128 && cout == 128) {   // persistent conv kernel: its tile scheduler's counters
                 ok = hipMalloc((void **)&w->d_sched, (size_t)SCHED_SLOTS * SCHED_WORDS * 4) == hipSuccess &&

@@ -42,6 +42,7 @@ struct sicn_weights {
     int8_t *d_w_mfma;
     int mfma_steps;
     int8_t *d_w_mfma16;    // the same tile sequence laid out for v_mfma_i32_16x16x64_i8 (k_mfma16.hip)
+    int8_t *d_w_mfma16x;   // deconv 128 -> 128: the tiles in the order the wide persistent kernel walks them (k_mfma16x.hip), or nullptr
     int8_t *d_bias_sigma;  // [cout] bias in sigma order == natural order (kept for clarity)
     // layer-0 (RGB -> cout) and layer-7 (cin -> RGB) layouts, or nullptr
     int8_t *d_w_l0;
@@ -76,6 +77,8 @@ hipError_t launch_mfma16(const LayerGeom &g, const sicn_weights &w, const uint8_
 // per wave (accumulators in AGPRs, one wave per SIMD); grid_cap > 0 limits the number of workgroups (tests)
 constexpr int WIDE_MIN_TILES = 4;   // automatic from this many tiles per CU on
 bool wide_supported(const LayerGeom &g);
+size_t mfma16x_deconv_stream_bytes(int cin, int cout);   // 0 where the wide deconv does not exist
+void pack_mfma16x_deconv_stream(const int8_t *w_okc, int cin, int cout, int8_t *dst);
 hipError_t launch_wide(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images, hipStream_t stream,
                        int in_layout, int out_layout, bool relu, int grid_cap);
 // k_mfma16p.hip: the software-pipelined conv / deconv kernels (tile_x = 16 | 32)

@@ -231,6 +231,27 @@ def test_wide_wave_tile_conv_matches_oracle(api, case, wave_tile, grid):
         assert np.array_equal(got[i], sicn_ref.conv2d_ref(x[i], W, b)), (i, np.count_nonzero(got[i] != sicn_ref.conv2d_ref(x[i], W, b)))
 
 
+WIDE_DECONV_CASES = [(128, 128, 8, 16, 34, 10, 1), (128, 128, 8, 16, 1, 1, 1), (128, 128, 8, 16, 65, 19, 1), (128, 128, 8, 16, 100, 45, 1),
+                     (128, 128, 4, 32, 33, 17, 1), (128, 128, 8, 16, 7, 5, 1), (128, 128, 8, 16, 150, 130, 1)]
+
+
+@pytest.mark.parametrize("grid", [0, 8, 16])
+@pytest.mark.parametrize("case", WIDE_DECONV_CASES)
+def test_wide_wave_tile_deconv_matches_oracle(api, case, grid):
+    """deconv 128 -> 128 in the wide persistent form (k_deconv_x): 4 phases per tile with the accumulator hand-over woven into the
+    next phase's first pass, the patch's two channel-group pairs in three rotating buffers; with 8 / 16 workgroups every one of
+    them walks through several tiles (n = 3 images, ragged tiles, single pixels), so every buffer rotation is exercised."""
+    rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + grid)
+    d = _mk_desc(*case)
+    W, b, words = _rand_params(rng, d)
+    x = rng.integers(0, 128, (3,) + d.in_shape, dtype=np.uint8)
+    x[0].reshape(-1)[::7] |= 0x80
+    got = _run_layer(api, d, words, b, x, tile_x=32, wave_tile=128, persistent_grid=grid)
+    for i in range(3):
+        ref = sicn_ref.deconv522_ref(x[i], W, b)
+        assert np.array_equal(got[i], ref), (i, np.count_nonzero(got[i] != ref))
+
+
 @pytest.mark.parametrize("wave_tile,grid", [(64, 0), (128, 0), (128, 8)])
 def test_wide_wave_tile_in_chain(api, wave_tile, grid):
     xin = _dev(_input("rng768")[None])

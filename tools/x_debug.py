@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Where does the wide deconv / conv differ from the oracle? usage: x_debug.py W H transposed [grid]"""
+import sys
+from pathlib import Path
+import numpy as np
+import torch
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+from oracle import sicn_ref
+from simple_image_compression_network_amd import api
+from simple_image_compression_network_amd.config import LayerDesc
+w, h, tr = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+grid = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+ow, oh = (2 * w, 2 * h) if tr else ((w + 1) // 2, (h + 1) // 2)
+d = LayerDesc(IFM_CH=128, IFM_ROW=w, IFM_COL=h, OFM_CH=128, OFM_ROW=ow, OFM_COL=oh, SIMD=8, PE=16, W_TILES=8 * 400, transposed=tr)
+rng = np.random.default_rng(1)
+W = rng.integers(-8, 8, (128, 5, 5, 128)).astype(np.int8)
+b = rng.integers(-128, 128, 128).astype(np.int8)
+words = sicn_ref.pack_finn_tiles(W, 8, 16)
+x = rng.integers(0, 128, (2,) + d.in_shape, dtype=np.uint8)
+fpw = api.FixedPointWeights(8, 4, 16, d.W_TILES, words)
+fn = api.deconv522 if tr else api.conv2d
+got = fn(d, fpw, b, torch.from_numpy(x).cuda(), None, 2, options={"tile_x": 32, "wave_tile": 128, "persistent_grid": grid}).cpu().numpy()
+for i in range(2):
+    ref = (sicn_ref.deconv522_ref if tr else sicn_ref.conv2d_ref)(x[i], W, b)
+    bad = got[i] != ref
+    print("image", i, "mismatches", bad.sum(), "of", bad.size)
+    if bad.any():
+        ys, xs, cs = np.nonzero(bad)
+        print("  rows", np.unique(ys)[:40], "\n  cols", np.unique(xs)[:80], "\n  channels", np.unique(cs)[:40], len(np.unique(cs)))
+        print("  (y%2, x%2) counts", {(a, c): int(((ys % 2 == a) & (xs % 2 == c)).sum()) for a in (0, 1) for c in (0, 1)})
