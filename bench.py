@@ -46,7 +46,7 @@ sys.path.insert(0, str(ROOT))
 
 PEAK_INT8_TOPS = 5000.0   # dense int8 MFMA = 2x the ~2.5 PFLOP/s bf16 dense peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0     # HBM3E spec
-KERNEL_SOURCES = ("k_common.hpp", "k_mfma16.hip", "k_mfma16p.hip", "k_mfma16w.hip", "k_mfma.hip", "k_rgb.hip", "k_generic.hip", "sicn_abi.hip")
+KERNEL_SOURCES = ("k_common.hpp", "k_mfma16.hip", "k_mfma16p.hip", "k_mfma16x.hip", "k_mfma.hip", "k_rgb.hip", "k_generic.hip", "sicn_abi.hip")
 
 
 def kernel_source_fingerprint() -> str:
@@ -69,6 +69,10 @@ def parse():
     ap.add_argument("--no-coder", action="store_true", help="skip the secondary with_coder measurement")
     ap.add_argument("--no-hyperprior", action="store_true", help="skip the secondary hyperprior (configs[4]) measurement")
     ap.add_argument("--no-host-io", action="store_true", help="skip the secondary host-buffer (PCIe-inclusive) measurement")
+    ap.add_argument("--no-configs", action="store_true", help="skip the secondary small configs (BASELINE.json configs[1], [2])")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained region")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="the timed loop and the per-layer table only (what profiles/collect_pmc.sh runs under rocprofv3)")
     ap.add_argument("--cpu-sample", type=int, nargs=2, default=[256, 256], metavar=("W", "H"))
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank) is the real thing; gloo lets several ranks share one GPU "
@@ -125,8 +129,87 @@ def cpu_baseline(image0: np.ndarray, sample_wh, gpu_latent0, gpu_out0):
     return res
 
 
+def small_configs(api, codec, dev):
+    """BASELINE.json configs[1] (256 x 256 analysis transform) and configs[2] (1080p encode + decode, without and with the
+    coder): one image each, timed by hipGraph replay (a chain of 8 - 12 launches of 10 - 50 us is what these are), outputs
+    compared with hashes the oracle made (tests/golden/appendix_a_hashes.json = SURVEY.md Appendix A, config_hashes.json)."""
+    import torch
+    out = {}
+    appx = json.loads((ROOT / "tests" / "golden" / "appendix_a_hashes.json").read_text())
+    cfgh = json.loads((ROOT / "tests" / "golden" / "config_hashes.json").read_text())
+
+    def replay_ms(graph, reps):
+        for _ in range(10):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            graph.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    def capture(fn):
+        import gc
+        fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=dev)
+        gc.collect()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                fn()
+        return g
+
+    sha = lambda t: hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()
+    # configs[1]: 256 x 256, analysis L0 - L3
+    net = api.EightLayersNet(256, 256, device=dev)
+    x = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (1, 256, 256, 3), dtype=np.uint8)).to(dev)
+    lat = torch.empty((1,) + net.descs[3].out_shape, dtype=torch.uint8, device=dev)
+    g = capture(lambda: net.analysis(x, lat))
+    ms = replay_ms(g, 300)
+    macs = sum(d.algorithmic_macs for d in net.descs[:4])
+    out["256x256_analysis"] = {"ms": round(ms, 4), "Mpixels_per_s": round(256 * 256 / ms / 1e3, 1),
+                               "mfma_frac": round(2.0 * macs / (ms * 1e-3) / 1e12 / PEAK_INT8_TOPS, 4),
+                               "latent_bit_exact": sha(lat[0]) == appx["layers"]["rng256"][3],
+                               "workload": "BASELINE.json configs[1]: one 256x256 RGB tile (seed 0), L0-L3 -> 16x16x192 latent, hipGraph replay"}
+    del net, g
+    # configs[2]: 1080p, encode + decode
+    W, H = 1920, 1080
+    net = api.EightLayersNet(W, H, device=dev)
+    x = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (1, H, W, 3), dtype=np.uint8)).to(dev)
+    rec = torch.empty((1,) + net.descs[-1].out_shape, dtype=torch.uint8, device=dev)
+    lat = torch.empty((1,) + net.descs[3].out_shape, dtype=torch.uint8, device=dev)
+    g = capture(lambda: net.forward(x, rec, lat))
+    ms = replay_ms(g, 200)
+    macs = sum(d.algorithmic_macs for d in net.descs)
+    want = cfgh["1080p_seed0"]
+    out["1080p_encode_decode"] = {"ms": round(ms, 4), "Mpixels_per_s": round(W * H / ms / 1e3, 1),
+                                  "mfma_frac": round(2.0 * macs / (ms * 1e-3) / 1e12 / PEAK_INT8_TOPS, 4),
+                                  "bit_exact": sha(lat[0]) == want["latent_sha256"] and sha(rec[0]) == want["recon_sha256"],
+                                  "workload": "BASELINE.json configs[2] without the coder: one 1920x1080 RGB image (seed 0), L0-L7, hipGraph replay"}
+    lat2 = torch.empty_like(lat)
+    coder = codec.LatentCoder(1, *net.descs[3].out_shape, image_width=W, image_height=H, device=dev)
+
+    def coded():
+        net.analysis(x, lat)
+        coder.encode(lat)
+        coder.decode(lat2)
+        net.synthesis(lat2, rec)
+
+    g2 = capture(coded)
+    ms = replay_ms(g2, 200)
+    coder.check()
+    out["1080p_with_coder"] = {"ms": round(ms, 4), "Mpixels_per_s": round(W * H / ms / 1e3, 1),
+                               "bits_per_pixel": round(8.0 * sum(coder.sizes()) / (W * H), 4),
+                               "bit_exact": sha(lat2[0]) == want["latent_sha256"] and sha(rec[0]) == want["recon_sha256"],
+                               "workload": "BASELINE.json configs[2]: analysis -> rANS-W encode -> decode -> synthesis, one hipGraph (the coder is this project's own)"}
+    return out
+
+
 def main():
     args = parse()
+    if args.headline_only:
+        args.no_coder = args.no_hyperprior = args.no_host_io = args.no_cpu_baseline = args.no_configs = args.no_sustained = True
     import torch
     import torch.distributed as dist
 
@@ -193,11 +276,20 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    dt = timed(step, args.steps)          # the headline: nothing but the 8 launches per step on the stream
+    # the per-layer table comes from a separate short loop (2 hipEvents per layer and step would sit inside `value` otherwise)
     net.profile(True)
     net.layer_ms(reset=True)
-    dt = timed(step, args.steps)
+    timed(step, max(10, min(args.steps, 40)))
     layer_ms, launches = net.layer_ms(reset=True)
     net.profile(False)
+    # a sustained region: the same step for >= 2 s (does the rate of the driver-sized region hold once the chip has settled?)
+    sustained = None
+    if not args.no_sustained:
+        ssteps = max(args.steps, int(2.0 / (dt / args.steps)) + 1)
+        sdt = timed(step, ssteps)
+        sustained = {"steps": ssteps, "seconds": round(sdt, 3), "ms_per_step": round(sdt / ssteps * 1e3, 3),
+                     "value": round(world * B * W * H * ssteps / sdt / 1e6, 2), "unit": "Mpixels/s"}
 
     # ---- the TIMED outputs against the committed oracle hashes ------------------------------------
     out_h, lat_h = out.cpu().numpy(), latent.cpu().numpy()
@@ -302,6 +394,31 @@ def main():
                         "latent), 2 device slots, events between the three streams (host_pipeline.HostPipeline)",
                 "note": "never `value`: the headline is HBM-resident; this is the rate a caller that owns host streams sees"}
         del hp, h_in, h_out, h_lat
+    # ---- secondaries of the multi-GPU runs (N > 1): strong scaling and the single-image band split ----------------------
+    strong = banded = None
+    if world > 1 and not args.headline_only:
+        from simple_image_compression_network_amd import dist as sdist
+        per = max(1, 64 // world)                      # BASELINE.json configs[3]: 64 images in all, 64 / N per rank
+        xs = x[:per] if per <= B else torch.cat([x] * ((per + B - 1) // B))[:per]
+        outs_s = torch.empty((per,) + net.descs[-1].out_shape, dtype=torch.uint8, device=dev)
+        lat_s = torch.empty((per,) + net.descs[3].out_shape, dtype=torch.uint8, device=dev)
+        net.forward(xs, outs_s, lat_s)
+        sdt = timed(lambda: net.forward(xs, outs_s, lat_s), max(4, args.steps // 2))
+        strong = {"value": round(world * per * W * H * max(4, args.steps // 2) / sdt / 1e6, 2), "unit": "Mpixels/s", "scaling": "strong",
+                  "images_per_gpu": per, "global_images": world * per, "ms_per_step": round(sdt / max(4, args.steps // 2) * 1e3, 3)}
+        # one 4K image over N ranks by horizontal bands (device-resident, one all-gather of the kept rows)
+        if args.backend == "nccl":
+            img = x[:1]
+            dist.broadcast(img, src=0)
+            bnet = sdist.BandedNet(W, H, world, rank, params=params, device=dev)
+            rec_b = bnet.forward(img)
+            bsteps = max(4, args.steps // 2)
+            bdt = timed(lambda: bnet.forward(img), bsteps)
+            whole = torch.empty((1,) + net.descs[-1].out_shape, dtype=torch.uint8, device=dev)
+            net.forward(img, whole, want_latent=False)
+            banded = {"ms_per_image": round(bdt / bsteps * 1e3, 3), "value": round(W * H * bsteps / bdt / 1e6, 2), "unit": "Mpixels/s",
+                      "bands": world, "equals_one_gpu_bytes": bool(torch.equal(rec_b, whole)),
+                      "note": "latency of ONE 4K image: each rank computes a band with 64 rows of recomputed halo, RCCL all-gather of the kept rows"}
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
@@ -366,6 +483,14 @@ def main():
         "whole_net_hbm_frac": round(sum(l["GBs"] * l["ms"] * 1e-3 for l in layers) / (dt / args.steps) / PEAK_HBM_GBS, 4)
         if all("GBs" in l for l in layers) else None,
     }
+    if sustained is not None:
+        res["sustained"] = sustained
+    if strong is not None:
+        res["strong_scaling"] = strong
+    if banded is not None:
+        res["banded"] = banded
+    if not args.no_configs and world == 1:
+        res["configs"] = small_configs(api, codec, dev)
     if pcie is not None:
         res["host_io"] = pcie
     if with_coder is not None:

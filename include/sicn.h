@@ -88,7 +88,7 @@ typedef struct sicn_layer_desc {
 typedef struct sicn_options {
     int32_t struct_bytes;    /* sizeof(sicn_options) of the caller's build                          */
     int32_t force_generic;   /* 1: the shape-agnostic kernel (k_generic) for every layer            */
-    int32_t mfma_shape;      /* 0 / 16: v_mfma_i32_16x16x64_i8 kernels; 32: the 32x32x32 kernels    */
+    int32_t mfma_shape;      /* 0 / 16: v_mfma_i32_16x16x64_i8 kernels; 32: the 32x32x32 kernels (ALT build only) */
     int32_t tile_x;          /* 0: by layer shape and grid size; 16 / 32: force that M-tile width   */
     int32_t strip_chunks;    /* 0: automatic; n: cut the vertical strips of the RGB layers into n   */
     int32_t no_phase_layout; /* 0: default; 1: never use the PHASE layout; 2: not towards layer 7   */
@@ -96,12 +96,14 @@ typedef struct sicn_options {
                              /*    pipelined 8 x 16 kernels give each workgroup 64 of the layer's 128 / 192 output     */
                              /*    channels (k_mfma16p.hip, launch_p)                                                 */
     int32_t wave_tile;       /* 0: automatic; 64: always the 64 x 128-per-wave kernels (two waves per SIMD); 128: the  */
-                             /*    128 x 128-per-wave kernel (one wave per SIMD) wherever it exists               */
-    int32_t prefetch;        /* 0: automatic; 1: never, 2: wherever it exists — the software-pipelined kernels         */
-                             /*    (k_mfma16p.hip); 3: as 2, and the PERSISTENT form (workgroups that walk through many */
-                             /*    tiles, k_conv_pp) wherever that exists, whatever the grid size                      */
-    int32_t persistent_grid; /* 0: two workgroups per CU (512); n: at most n (rounded down to a multiple of 8, >= 8) —  */
-                             /*    tests use it to give every workgroup many tiles of a small input                    */
+                             /*    WIDE PERSISTENT kernels (k_mfma16x.hip: one workgroup of 4 waves per CU walks through */
+                             /*    16 x 32 tiles, 128 x 128 outputs per wave) wherever they exist (conv / deconv        */
+                             /*    128 -> 128), whatever the grid size; automatic: from 4 tiles per CU on              */
+    int32_t prefetch;        /* 0: automatic; 1: never, 2 / 3: wherever it exists — the software-pipelined kernels      */
+                             /*    (k_mfma16p.hip) for the shapes and grids the wide kernels do not take               */
+    int32_t persistent_grid; /* 0: one workgroup per CU (256); n: at most n (rounded down to a multiple of 8, >= 8)     */
+                             /*    workgroups for the wide persistent kernels — tests use it to make every workgroup    */
+                             /*    walk through many tiles of a small input                                            */
     int32_t reserved[6];
 } sicn_options;
 
@@ -110,11 +112,14 @@ typedef struct sicn_net sicn_net;         /* a chain of layers (the 8-layer net,
 
 /* Library / device ------------------------------------------------------------------------- */
 int sicn_version(void);                  /* 1000*major + minor                                 */
+int sicn_has_alt_kernels(void);          /* 1: this build carries the alternate kernel families (the 32x32x32 MFMA kernels of
+                                          * k_mfma.hip, `make ALT=1` -> libsicn_alt.so: parity tests only); 0: the product build,
+                                          * which rejects sicn_options.mfma_shape = 32 with SICN_EINVAL */
 const char *sicn_strerror(int code);
 int sicn_validate_desc(const sicn_layer_desc *desc); /* pure host check, no GPU needed         */
 /* Fills *opt with the library defaults (= all zero, overridden by the SICN_MFMA_SHAPE, SICN_TILE_X,
- * SICN_STRIP_CHUNKS, SICN_NO_PHASE_LAYOUT, SICN_SPLIT_N, SICN_FORCE_GENERIC environment variables as
- * they were when the library was loaded). */
+ * SICN_STRIP_CHUNKS, SICN_NO_PHASE_LAYOUT, SICN_SPLIT_N, SICN_WAVE_TILE, SICN_PREFETCH, SICN_FORCE_GENERIC environment
+ * variables as they were when the library was loaded; out-of-range values are ignored with one warning on stderr). */
 void sicn_options_init(sicn_options *opt);
 
 /* Weights ---------------------------------------------------------------------------------- */
@@ -122,11 +127,9 @@ void sicn_options_init(sicn_options *opt);
  * holding SIMD nibbles (element s in bits [4s,4s+4), weights.hpp:134-139), each word stored in
  * `word_bytes` (1,2,4 or 8) little-endian bytes; `bias` = HOST int8[OFM_CH].  Only desc fields
  * IFM_CH, OFM_CH, SIMD, PE, W_TILES, transposed are used (weights do not depend on image size).
- * Synchronous (uploads to the current device).
- * A conv 128 -> 128 handle also owns 16 small blocks of device memory for the tile scheduler of the persistent
- * kernel: every launch through the handle takes the next block and zeroes its counters on its own stream, so
- * launches on different streams (or graph nodes of different captures) do not share counters as long as fewer
- * than 16 launches of the SAME handle are in flight at once. */
+ * Synchronous (uploads to the current device).  A handle is immutable after creation: any number of launches, streams,
+ * host threads and captured graphs may use it at the same time (the persistent kernels deal their tiles statically and
+ * keep no scheduler state). */
 int sicn_weights_from_finn_tiles(const sicn_layer_desc *desc, const void *m_weights, int word_bytes,
                                  const int8_t *bias, sicn_weights **out);
 void sicn_weights_free(sicn_weights *w);

@@ -23,34 +23,65 @@ def short(n):
     return n.replace("void sicn::", "").replace("sicn::", "").split("(")[0]
 
 
+def is_layer_kernel(name):
+    return name.startswith(("k_l0", "k_l7", "k_conv", "k_deconv", "k_mfma", "k_generic"))
+
+
+def by_layer(rows, key):
+    """The headline-only bench launches nothing but the net's 8 layers, in order, step after step: dispatch i (sorted by `key`)
+    of the layer kernels is layer i mod 8.  (Kernel name + grid no longer identifies a layer: the wide persistent kernels run
+    layers 1 / 2 and 5 / 6 with the same 256 workgroups.)  Checked: every layer sees one kernel name only."""
+    rows = sorted((r for r in rows if is_layer_kernel(short(r["Kernel_Name"]))), key=key)
+    out = collections.defaultdict(list)
+    for i, r in enumerate(rows):
+        out[i % 8].append(r)
+    for l, rs in out.items():
+        names = {short(r["Kernel_Name"]) for r in rs}
+        if len(names) != 1:
+            raise SystemExit(f"layer {l}: dispatch order does not repeat with period 8: {names}")
+    return out
+
+
 def counters(d):
-    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    rows = []
     for f in glob.glob(str(d) + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            name = short(r["Kernel_Name"])
-            if "k_" not in name:
-                continue
-            key = f'{name} {r.get("Grid_Size", r.get("Grid_Size_X", ""))}'
-            acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+        rows += list(csv.DictReader(open(f)))
+    if not rows:
+        return {}
+    # one row per (dispatch, counter): order the dispatches first
+    disp = {}
+    for r in rows:
+        disp.setdefault(int(r["Dispatch_Id"]), r)
+    layers = by_layer(disp.values(), key=lambda r: int(r["Dispatch_Id"]))
+    layer_of = {int(r["Dispatch_Id"]): l for l, rs in layers.items() for r in rs}
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    names = {}
+    for r in rows:
+        l = layer_of.get(int(r["Dispatch_Id"]))
+        if l is None:
+            continue
+        names[l] = short(r["Kernel_Name"])
+        acc[l][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {f"layer {l} {names[l]}": {c: sum(v) / len(v) for c, v in cs.items()} for l, cs in acc.items()}
 
 
 stats = glob.glob(str(out / "stats") + "/**/*kernel_stats.csv", recursive=True)
 if stats:
     shutil.copy(stats[0], ROOT / "profiles" / f"{tag}_kernel_stats.csv")
-# the same trace per (kernel, grid size): one kernel serves several layers (layer 5 and 6 are the same deconv kernel), and the
-# bench line's roofline.avg_launch_ms is per LAYER — this is the table it has to agree with
-per = collections.defaultdict(list)
+# per LAYER: this is the table the bench line's roofline.avg_launch_ms has to agree with
+per = {}
+trace = []
 for f in glob.glob(str(out / "stats") + "/**/*kernel_trace.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        name = short(r["Kernel_Name"])
-        grid = r.get("Grid_Size", r.get("Grid_Size_X", ""))
-        per[(name, grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-if per:
+    trace += list(csv.DictReader(open(f)))
+if trace:
+    layers = by_layer(trace, key=lambda r: int(r["Start_Timestamp"]))
     with open(ROOT / "profiles" / f"{tag}_per_layer_dispatch.csv", "w") as fh:
-        fh.write("kernel,grid_threads,calls,avg_ns,min_ns,max_ns\n")
-        for (name, grid), v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
-            fh.write(f'"{name}",{grid},{len(v)},{sum(v) / len(v):.0f},{min(v)},{max(v)}\n')
+        fh.write("layer,kernel,grid_threads,calls,avg_ns,min_ns,max_ns\n")
+        for l in sorted(layers):
+            v = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in layers[l]]
+            r0 = layers[l][0]
+            per[l] = v
+            fh.write(f'{l},"{short(r0["Kernel_Name"])}",{r0.get("Grid_Size", r0.get("Grid_Size_X", ""))},{len(v)},{sum(v) / len(v):.0f},{min(v)},{max(v)}\n')
 fetch, write, sq = counters(out / "pmc_fetch"), counters(out / "pmc_write"), counters(out / "pmc_sq")
 kernels = {}
 for k in sorted(set(fetch) | set(write) | set(sq)):
@@ -76,11 +107,11 @@ for k in sorted(set(fetch) | set(write) | set(sq)):
 
 # dominant layer of the 8 x 4K bench: the largest average launch in the stats run
 from bench import kernel_source_fingerprint  # noqa: E402
-summary = {"_about": "rocprofv3 --pmc passes of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-coder` (8 x 4K images per "
-                     "launch). Separate passes {FETCH_SIZE,TCC_HIT_sum}, {WRITE_SIZE,TCC_MISS_sum}, {SQ_*,GRBM_GUI_ACTIVE}. "
+summary = {"_about": "rocprofv3 --pmc passes of `python3 bench.py --headline-only --steps 3 --warmup 1` (8 x 4K images per "
+                     "launch; nothing but the 8 layers runs, so dispatch i is layer i mod 8). Separate passes {FETCH_SIZE,TCC_HIT_sum}, {WRITE_SIZE,TCC_MISS_sum}, {SQ_*,GRBM_GUI_ACTIVE}. "
                      "FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide "
                      "streaming read, so the x2 figure is the one to compare with byte counts (MI355X_MICROARCH.md, HBM). "
-                     "mfma_pipe_util = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs). Key = kernel + grid size.",
+                     "mfma_pipe_util = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs). Key = layer + kernel.",
            "kernel_source_fingerprint": kernel_source_fingerprint(), "kernels": kernels}
 try:
     line = [l for l in open(out / "bench_under_rocprof.json") if l.startswith("{")][-1]
@@ -90,24 +121,19 @@ try:
     summary["dominant_kernel_algorithmic_bytes_per_launch"] = b["roofline"]["algorithmic_bytes"]
     summary["dominant_kernel_avg_launch_ms_bench"] = b["roofline"]["avg_launch_ms"]
     summary["bench_under_rocprof"] = {k: b[k] for k in ("value", "ms_per_step", "layers", "output_bit_exact")}
-    # the dominant layer's kernel: the MFMA conv/deconv kernel with the largest grid among its family
-    fam = "true" if b["layers"][dom]["kernel"] == "mfma_deconv" else "false"
-    kind = b["layers"][dom]["kernel"]
-    if kind.startswith("mfma"):
-        pre = "k_deconv_p" if kind == "mfma_deconv" else "k_conv_p"
-        cands = [k for k in kernels if k.startswith(pre)] or [k for k in kernels if k.startswith("k_mfma16_t") and f", {fam}," in k]
-    else:
-        cands = [k for k in kernels if k.startswith("k_l0" if dom == 0 else "k_l7")]
-    if cands:
-        best = max(cands, key=lambda k: int(k.split()[-1] or 0))
+    best = next((k for k in kernels if k.startswith(f"layer {dom} ")), None)
+    if best:
         e = kernels[best]
         summary["dominant_kernel"] = best
         if "fetch_bytes_x2_gfx950_correction" in e and "write_bytes" in e:
             summary["dominant_kernel_hbm_bytes_per_launch"] = int(e["fetch_bytes_x2_gfx950_correction"] + e["write_bytes"])
-        name, grid = best.rsplit(" ", 1)
-        if (name, grid) in per:
-            v = per[(name, grid)]
+        if dom in per:
+            v = per[dom]
             summary["dominant_kernel_avg_launch_ms_rocprof"] = round(sum(v) / len(v) / 1e6, 4)
+            ops = 2.0 * 8 * 518400 * 128 * 128 * 25 if dom in (1, 6) else None
+            if ops:
+                summary["dominant_kernel_roofline_frac_from_rocprof"] = round(ops / (sum(v) / len(v) * 1e-9) / 5e15, 4)
+    summary["per_layer_avg_ms_rocprof"] = {str(l): round(sum(v) / len(v) / 1e6, 4) for l, v in sorted(per.items())}
 except Exception as ex:  # noqa: BLE001
     summary["_warning"] = f"bench line not parsed: {ex}"
 (ROOT / "profiles" / f"{tag}_pmc_summary.json").write_text(json.dumps(summary, indent=1) + "\n")

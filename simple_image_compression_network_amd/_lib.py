@@ -37,6 +37,7 @@ def make_options(**kw) -> "COptions":
 _descp = ctypes.POINTER(CLayerDesc)
 ABI = {
     "sicn_version": (_i, []),
+    "sicn_has_alt_kernels": (_i, []),
     "sicn_strerror": (ctypes.c_char_p, [_i]),
     "sicn_validate_desc": (_i, [_descp]),
     "sicn_weights_from_finn_tiles": (_i, [_descp, _vp, _i, _vp, ctypes.POINTER(_vp)]),

@@ -459,14 +459,6 @@ static hipError_t launch_one(const LayerGeom &g, const sicn_weights &w, const ui
                                : launch_var<NQ, NTJ, DECONV, 0>(g, w, in, out, n_images, stream, in_layout, out_layout);
 }
 
-// shapes the 16x16x64 kernels (k_mfma16.hip) serve: the reference net's L1-L6 plus the hyperprior stacks'
-// conv 192 -> 128 and deconv 128 -> 192
-bool mfma_supported(int cin, int cout, int transposed)
-{
-    const bool io = (cin == 128 || cin == 192) && (cout == 128 || cout == 192) && !(cin == 192 && cout == 192);
-    (void)transposed;
-    return io;
-}
 // shapes the 32x32x32 kernels of this file are instantiated for (the reference net only)
 bool mfma32_supported(int cin, int cout, int transposed)
 {

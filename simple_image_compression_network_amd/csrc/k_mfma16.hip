@@ -417,10 +417,6 @@ static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint
             // (measured, r02: at 192 - 255 tiles the split is a wash or a loss; at <= 72 it takes 20 - 35 % off the layer)
             const long tiles16 = (long)((MW + 15) / 16) * ((MH + TILE_Y - 1) / TILE_Y) * n_images;
             const bool split = tx == 16 && (o.split_n > 1 || (o.split_n == 0 && tiles16 <= 128));
-            // workgroups that walk through many tiles (k_conv_pp): where every one of the 512 residents gets at least 4
-            const long tiles_tx = (long)((MW + tx - 1) / tx) * ((MH + TILE_Y - 1) / TILE_Y) * n_images;
-            if (persistent_supported(g, tx) && (o.prefetch == 3 || (o.prefetch == 0 && tiles_tx >= 4 * 512)))
-                return launch_persistent(g, w, in, out, n_images, stream, in_layout, out_layout, relu, o.persistent_grid);
             // deconv 192 -> 128 on a full grid (>= 1024 tiles): three passes per tap keep the pipelined form from double-buffering its weight
             // fragments, and there the plain kernel is 7 % faster (layer 4 at 8 x 4K: 0.159 against 0.171 ms); with the
             // output-channel split (small grids) the pipelined one wins
@@ -430,6 +426,13 @@ static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint
     }
     return narrow ? launch16_tx<NQ, NT16, DECONV, 16>(g, w, in, out, n_images, stream, in_layout, out_layout, relu)
                   : launch16_tx<NQ, NT16, DECONV, 32>(g, w, in, out, n_images, stream, in_layout, out_layout, relu);
+}
+
+// shapes the 16x16x64 kernels serve: the reference net's L1-L6 plus the hyperprior stacks' conv 192 -> 128 and deconv 128 -> 192
+bool mfma_supported(int cin, int cout, int transposed)
+{
+    (void)transposed;
+    return (cin == 128 || cin == 192) && (cout == 128 || cout == 192) && !(cin == 192 && cout == 192);
 }
 
 hipError_t launch_mfma16(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,

@@ -14,9 +14,10 @@
 //     second set; only the pixel fragments (used by every weight tile of the pass) are double-buffered (+16 VGPRs);
 //   * the barrier that ends pass k therefore publishes the weight tiles of pass k+2: the ring runs 4 passes ahead (PFP = 8);
 //   * a pass's LDS-DMA requests are issued behind its first MFMA group: the MFMA pipe restarts right after the barrier.
-// Also in this file: the output-channel split of the 8 x 16 kernels for grids smaller than the chip (NT16 < NTF, launch_p),
-// k_conv_pp — conv 128 -> 128 by PERSISTENT workgroups that walk through many tiles, dealt by a per-XCD ticket counter (its
-// header comment has the why and the how) — and, under -DSICN_STAMP only, in-kernel s_memtime stamps for tools/*_stamps.py.
+// Also in this file: the output-channel split of the 8 x 16 kernels for grids smaller than the chip (NT16 < NTF, launch_p) and,
+// under -DSICN_STAMP only, in-kernel s_memtime stamps for tools/*_stamps.py.  (Round 2's persistent conv kernel k_conv_pp, with
+// its per-XCD ticket scheduler in device memory owned by the weights handle, is gone: full-size grids now run the wide persistent
+// kernels of k_mfma16x.hip, which deal their tiles statically and keep no scheduler state at all.)
 // Hazards hipcc cannot see inside asm are covered by hand: s_nop between a VALU write and an asm MFMA that reads it as C, an
 // asm statement that keeps the C operand's registers live (and waits) behind the MFMAs that read them, s_nop before the
 // epilogue reads the accumulators.
@@ -576,279 +577,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_p(const uint8_t *__restrict__ i
 #endif
 }
 
-// =====================================================================================================================
-// conv2d<>, PERSISTENT form (round 2, tools/pass_stamps.py).  In-kernel stamps on layer 1 showed where the pipelined kernel's
-// 27 % of idle MFMA pipe are: NOT in the pass loop (1045 cycles per pass for two waves x 512 pipe cycles: 98 % busy) but in
-// the 11k-cycle prologue and the 7.6k-cycle epilogue of every one-tile workgroup (71k cycles of life) — and while one of a
-// CU's two workgroups is in them its mate's loop hardly speeds up (972 cycles per pass against 680 for a workgroup alone on a
-// CU): the bursts of LDS-DMA requests and the drained pipelines of the one get in the way of the other.
-// Here a workgroup walks through MANY tiles and the pipeline never drains between them:
-//   * the rolling plane refresh already fetches "the next channel group" under the current one; in a tile's LAST group that is
-//     group 0 of the workgroup's NEXT tile (its piece offsets and image replace the current ones after pass 39, when the last
-//     refresh for the current tile has been requested; plane 3, which is refreshed at the START of a group, switches at the
-//     tile boundary);
-//   * the weight stream simply wraps: ring slot = running tile count mod 8, and since a tile has 100 K-steps = 4 mod 8 the two
-//     ring halves swap names at every tile boundary (one scalar added to the compile-time slot offsets);
-//   * the last pass of a tile fetches the first fragments of the next one; between them sit only the ReLU / pack / 8 stores per
-//     wave and the bias re-initialisation of the accumulators; the stores are older than the requests of the next passes, so
-//     the first two counted waits of a tile allow for them (EXTRA, as between the phases of the deconv kernel).
-// Workgroup l of G = 2 x 256 belongs to XCD l % 8 and takes every (G / 8)-th tile of that XCD's contiguous range.
-// =====================================================================================================================
-struct ConvPPCtx {
-    uint8_t *patch, *ring;
-    uint32_t ring_sw;                             // 0 or half a ring (4 tiles): the frame of this tile's logical ring slots
-    const int8_t *wstream;
-    const uint8_t *in_img;                        // the image the plane REFRESH reads (moves to the next tile's ahead of the tile)
-    int in_img_bytes;
-    const uint8_t *lane_pix, *lane_wt;
-    uint32_t qstride;
-    int lane, w;
-};
-
-template <int TX, int NT16>
-__host__ __device__ constexpr int conv_in_flight_pp(int P, int npass)   // requests of passes P and P - 1 (FLIGHT = 2), wrapping
-{
-    return conv_requests_p<TX, NT16>(P) + conv_requests_p<TX, NT16>((P + npass - 1) % npass);
-}
-
-template <int NQ, int TX, int NT16, int PF, int P, int NPASS>
-__device__ __forceinline__ void conv_pass_pp(v4i (&acc)[Geo<TX>::NC][NT16], const v4i (&wc)[NT16], v4i (&wn)[NT16],
-                                             const v4i (&pc)[Geo<TX>::NC], v4i (&pn)[Geo<TX>::NC], const ConvPPCtx &c,
-                                             const uint32_t (&poff)[4][Geo<TX>::SLOTS], bool stores_in_flight)
-{
-    static_assert(PF == 8 && Ring<PF>::FLIGHT == 2 && (2 * NPASS) % PF == 4, "the ring halves swap at a tile boundary");
-    constexpr int ALLOC = Geo<TX>::ALLOC, S = Geo<TX>::SLOTS, TB = WTile<NT16>::TB, NPB = WTile<NT16>::NPB, WR = WTile<NT16>::WR;
-    constexpr int tA = (2 * P) % 25, tB = (2 * P + 1) % 25, qA = (2 * P) / 25, qB = (2 * P + 1) / 25;
-    constexpr int rpA = refresh_plane_p(tA, S), rpB = refresh_plane_p(tB, S);
-    // weight tiles through a buffer descriptor (scalar base + scalar tile / piece offset + one per-lane dword): the 64-bit
-    // per-lane source pointer of global_load_lds cost two VGPRs the tile loop does not have (it was spilled)
-    auto wtile = [&](auto idx_tag) {   // K-step idx of the running stream: source wraps at the tile's 2 NPASS steps, the slot does not
-        constexpr int idx = decltype(idx_tag)::value, src_tile = idx % (2 * NPASS), slot = idx % PF;
-        __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)c.wstream, 0, 2 * NPASS * TB, 0x00020000);
-        uint8_t *dst = c.ring + (((uint32_t)(slot * TB) + c.ring_sw) & (uint32_t)(PF * TB - 1));
-#pragma unroll
-        for (int r = 0; r < WR; r++) {
-            int piece = r * 4 + c.w;
-            if (piece >= NPB) piece -= 2;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(dst + piece * 1024), 16, (uint32_t)(c.lane * 16),
-                                                     (uint32_t)(src_tile * TB + piece * 1024), 0, 0);
-        }
-    };
-    auto dma = [&]() {
-#ifndef SICN_X_NOPDMA   // experiment (wrong results): the passes without their plane refresh requests
-        if constexpr (rpA >= 0)
-            load_piece<ALLOC>(c.patch, c.in_img, c.in_img_bytes, rpA, refresh_slot_p(tA, S) * 4 + c.w,
-                              poff[rpA][refresh_slot_p(tA, S)] + (uint32_t)((rpA == 3) ? qA : (qA + 1) % NQ) * c.qstride);
-        if constexpr (rpB >= 0)
-            load_piece<ALLOC>(c.patch, c.in_img, c.in_img_bytes, rpB, refresh_slot_p(tB, S) * 4 + c.w,
-                              poff[rpB][refresh_slot_p(tB, S)] + (uint32_t)((rpB == 3) ? qB : (qB + 1) % NQ) * c.qstride);
-#endif
-#ifndef SICN_X_NOWDMA   // experiment (wrong results): the passes without their weight requests
-        wtile(std::integral_constant<int, 2 * P + PF>{});
-        wtile(std::integral_constant<int, 2 * P + 1 + PF>{});
-#endif
-    };
-    constexpr int PN = (P + 1) % NPASS;                       // taps wrap into the next tile ...
-    constexpr uint32_t offNA = tap_off_p<TX>((2 * PN) % 25), offNB = tap_off_p<TX>((2 * PN + 1) % 25);
-    constexpr int slotN = (2 * (P + 1)) % PF;                 // ... the ring does not
-    // (the upper lane half takes the odd K-step; recomputed from the lane id, as is the ring frame from a scalar: two VGPRs
-    // fewer held across the tile loop, which has none to spare)
-    const bool hi = (c.lane & 32) != 0;
-    const uint8_t *pixn = c.lane_pix + (hi ? offNB : offNA);
-    const uint8_t *wtn = c.lane_wt + ((((uint32_t)(slotN * TB) + c.ring_sw) & (uint32_t)(PF * TB - 1)) + (hi ? (uint32_t)TB : 0u));
-    const v4i none[NT16 / 4] = {};
-    constexpr int NSTORE = Geo<TX>::NC * NT16 / 4;
-    pass_p<TX, NT16, conv_in_flight_pp<TX, NT16>(P, NPASS), (P < 2 ? NSTORE : 0), false, false>(acc, wc, wn, pc, pn, pixn, wtn,
-                                                                                                stores_in_flight, none, dma);
-}
-
-template <int NQ, int TX, int NT16, int PF, int P, int END, int NPASS>
-__device__ __forceinline__ void conv_passes_pp(v4i (&acc)[Geo<TX>::NC][NT16], v4i (&wbuf)[NT16], v4i (&pa)[Geo<TX>::NC],
-                                               v4i (&pb)[Geo<TX>::NC], const ConvPPCtx &c, const uint32_t (&poff)[4][Geo<TX>::SLOTS],
-                                               bool stores_in_flight)
-{
-    if constexpr ((P & 1) == 0)
-        conv_pass_pp<NQ, TX, NT16, PF, P, NPASS>(acc, wbuf, wbuf, pa, pb, c, poff, stores_in_flight);
-    else
-        conv_pass_pp<NQ, TX, NT16, PF, P, NPASS>(acc, wbuf, wbuf, pb, pa, c, poff, stores_in_flight);
-    if constexpr (P + 1 < END) conv_passes_pp<NQ, TX, NT16, PF, P + 1, END, NPASS>(acc, wbuf, pa, pb, c, poff, stores_in_flight);
-}
-
-template <int NQ, int NT16, int TX, int PF>
-__global__ __launch_bounds__(256, 2) void k_conv_pp(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
-                                                    const int8_t *__restrict__ wstream, const int8_t *__restrict__ bias, int IW, int IH,
-                                                    int OW, int OH, int tiles_x, int n_tiles, int n_images, int in_layout, int out_layout,
-                                                    uint32_t act_floor, uint32_t *__restrict__ sched)
-{
-    constexpr int CIN = NQ * 32, COUT = NT16 * 16, NC = Geo<TX>::NC, NPASS = 25 * NQ / 2, SW = 40;
-    static_assert(NQ == 4 && TX == 32, "pass 39 is the last one that requests a refresh for the current tile");
-    constexpr int PX = Geo<TX>::PX, ALLOC = Geo<TX>::ALLOC, SLOTS = Geo<TX>::SLOTS, TB = WTile<NT16>::TB;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *patch = smem, *ring = smem + 4 * ALLOC;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pos = lane & 15, g = lane >> 4, hi = g >> 1, half = g & 1;
-    const int in_img_bytes = IH * IW * CIN, out_img_bytes = OH * OW * COUT;
-    const TensorMap im = tensor_map(in_layout, CIN, IW, IH), om = tensor_map(out_layout, COUT, OW, OH);
-    // this workgroup's tiles: XCD x = l % 8 owns [x * per, (x + 1) * per) of the list; its gridDim.x / 8 workgroups interleave
-    const int total = n_tiles * n_images, per = (total + N_XCD - 1) / N_XCD;
-    const int xcd = (int)blockIdx.x % N_XCD, stride = (int)gridDim.x / N_XCD;
-    int item = xcd * per + (int)blockIdx.x / N_XCD;
-    const int item_end = min(total, (xcd + 1) * per);
-    if (item >= item_end) return;
-    auto coord = [&](int it) {
-        const int img = it / n_tiles, tile = it - img * n_tiles, ty = tile / tiles_x;
-        return TileCoord{img, ty * TILE_Y, (tile - ty * tiles_x) * TX, true};
-    };
-    TileCoord tc = coord(item);
-    uint32_t poff[4][SLOTS];
-    auto set_poff = [&](const TileCoord &t, int pl_begin, int pl_end, bool valid) {
-        // the lane's patch positions are loop-invariant and hipcc would keep them (12 registers the loop does not have:
-        // they were spilled, and a scratch reload is a vmcnt(0) wait in the middle of the DMA pipeline): recomputed every
-        // time, from a lane id that is itself recomputed (two v_mbcnt) rather than kept
-        int lane_l;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_l));
-#pragma unroll
-        for (int pl = 0; pl < 4; pl++)
-            if (pl >= pl_begin && pl < pl_end) {
-#pragma unroll
-                for (int slot = 0; slot < SLOTS; slot++) {
-                    const PieceSrc ps = piece_src<TX>(im, slot * 4 + w, lane_l, t.Y0 - 1, t.X0 - 1, 2, pl >> 1, pl & 1, IW, IH);
-                    poff[pl][slot] = (valid && ps.ok) ? ps.off : OOB;
-                }
-            }
-    };
-    set_poff(tc, 0, 4, true);
-    ConvPPCtx ctx{patch, ring, 0u, wstream, in + (size_t)tc.img * in_img_bytes, in_img_bytes,
-                  patch + (uint32_t)(((2 * w) * PX + pos) * 32 + half * 16), ring + (uint32_t)(pos * 32 + half * 16), im.grp, lane, w};
-    // ---- prologue of the FIRST tile only: planes 0..2 of group 0 (plane 3 arrives in steps 1..) + PF weight tiles -----------
-#pragma unroll
-    for (int pl = 0; pl < 3; pl++)
-#pragma unroll
-        for (int slot = 0; slot < SLOTS; slot++) load_piece<ALLOC>(patch, ctx.in_img, in_img_bytes, pl, slot * 4 + w, poff[pl][slot]);
-#pragma unroll
-    for (int s = 0; s < PF; s++) load_wtile_p<NT16, NT16, PF>(ring, wstream, s, lane, w);
-    v4i acc[NC][NT16];
-    // accumulators start at the bias: register r of tile (c, j) is channel 64 (j>>2) + 16 g + 4 (j&3) + r.  The bias comes
-    // through SCALAR loads (uniform address, lgkmcnt) and a per-lane select of its g-th quarter: a vector load here would have
-    // to wait for every LDS-DMA request ahead of it (vmcnt retires in order) at every tile boundary.
-    auto init_acc = [&]() {
-        int lane_i;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_i));
-        const int gi = lane_i >> 4;
-#pragma unroll
-        for (int J = 0; J < NT16 / 4; J++) {
-            const uint4 *bs = (const uint4 *)(bias + 64 * J);   // 64 bytes: channels 64 J .. 64 J + 63, quarter g = 16 g .. 16 g + 15
-            const uint4 q0 = bs[0], q1 = bs[1], q2 = bs[2], q3 = bs[3];
-            const uint32_t b4[4] = {gi == 0 ? q0.x : gi == 1 ? q1.x : gi == 2 ? q2.x : q3.x, gi == 0 ? q0.y : gi == 1 ? q1.y : gi == 2 ? q2.y : q3.y,
-                                    gi == 0 ? q0.z : gi == 1 ? q1.z : gi == 2 ? q2.z : q3.z, gi == 0 ? q0.w : gi == 1 ? q1.w : gi == 2 ? q2.w : q3.w};
-#pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
-                v4i v;
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = (int)(int8_t)(b4[jj] >> (8 * r));
-#pragma unroll
-                for (int c = 0; c < NC; c++) acc[c][4 * J + jj] = v;
-            }
-        }
-        // VALU-initialised accumulators -> asm MFMA reading them as C: the wait states hipcc cannot know about
-#pragma unroll
-        for (int c = 0; c < NC; c++)
-#pragma unroll
-            for (int j = 0; j < NT16; j++) asm volatile("" : "+v"(acc[c][j]));
-        asm volatile("s_nop 3" ::: "memory");
-    };
-    wait_vmcnt<0>();
-    block_barrier();
-    v4i wbuf[NT16], pa[NC], pb[NC];
-    {   // fragments of pass 0: taps 0 / 1 of group 0, ring slots 0 / 1
-        const uint8_t *p0 = ctx.lane_pix + (hi ? tap_off_p<TX>(1) : tap_off_p<TX>(0));
-        const uint8_t *w0 = ctx.lane_wt + hi * TB;
-#pragma unroll
-        for (int r = 0; r < NT16; r++) wbuf[r] = *(const v4i *)(w0 + r * 16 * 32);
-#pragma unroll
-        for (int r = 0; r < NC; r++) pa[r] = *(const v4i *)(p0 + ((r / Geo<TX>::XT) * PX + (r % Geo<TX>::XT) * 16) * 32);
-    }
-    init_acc();
-    // the first two tiles are fixed; tickets number the ones from 2 * stride on.  (readfirstlane: these are wave-uniform, and a
-    // VGPR spent on them is a VGPR spilled — with a vmcnt(0) at its reload)
-    int next = __builtin_amdgcn_readfirstlane(item + stride), tiles_done = __builtin_amdgcn_readfirstlane(0);
-#ifdef SICN_X_PP_SLEEP   // experiment: put a CU's two residents half a pass out of phase
-    if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_sleep(SICN_X_PP_SLEEP);
-#endif
-#ifdef SICN_STAMP
-    const unsigned long long pp_t0 = __builtin_amdgcn_s_memtime(), pp_r0 = __builtin_amdgcn_s_memrealtime();
-    int pp_tiles = 0;
-#endif
-#pragma unroll 1
-    for (;;) {
-#ifdef SICN_STAMP
-        pp_tiles++;
-#endif
-        {   // keep hipcc from hoisting the 100 weight-tile source addresses of a tile out of the tile loop (it did: 223 spilled VGPRs)
-            const int8_t *ws = ctx.wstream;
-            asm volatile("" : "+s"(ws));
-            ctx.wstream = ws;
-        }
-        // Tiles come from a per-XCD ticket counter: workgroups do NOT take the same time per tile (47k to 68k cycles, measured),
-        // and with a fixed share the slowest one sets the kernel's time.  A workgroup always knows its current AND its next tile
-        // (the next one's planes are fetched from pass 40 on); the ticket for the tile after that is drawn by wave 0 in the
-        // epilogue (see there) and read by every wave from the workgroup's mailbox a few passes into the following tile.
-        conv_passes_pp<NQ, TX, NT16, PF, 0, 8, NPASS>(acc, wbuf, pa, pb, ctx, poff, tiles_done > 0);
-        if (sched && tiles_done > 0) {   // the ticket drawn in the previous epilogue: posted before the barriers of passes 0..3
-            uint32_t ticket;
-            asm volatile("s_nop 7\n\ts_dcache_inv\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ticket) : "s"(sched + N_XCD + blockIdx.x) : "memory");
-            next = __builtin_amdgcn_readfirstlane(xcd * per + 2 * stride + (int)ticket);
-        }
-        conv_passes_pp<NQ, TX, NT16, PF, 8, SW, NPASS>(acc, wbuf, pa, pb, ctx, poff, false);
-        // every refresh for THIS tile has been requested: from here on planes 0..2 are fetched for the next tile
-        const bool has_next = next < item_end;
-        const TileCoord tn = coord(has_next ? next : item);
-        set_poff(tn, 0, 3, has_next);
-        ctx.in_img = in + (size_t)tn.img * in_img_bytes;
-        conv_passes_pp<NQ, TX, NT16, PF, SW, NPASS, NPASS>(acc, wbuf, pa, pb, ctx, poff, false);
-        {   // the epilogue's per-lane offsets: recomputed from a fresh lane id for the same reason as in set_poff
-            int lane_e;
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
-            if (sched && has_next && w == 0) {
-                // one lane draws the ticket and posts it.  (s_nop: the address SGPRs may come straight from a v_readlane — SGPR
-                // spills live in VGPR lanes — and hipcc's hazard recogniser does not look inside asm: without the wait states the
-                // atomic went to a stale address and faulted.)  Spelled out in asm: hipcc would put a vmcnt(0) right behind the
-                // atomic; here the wait sits behind nothing younger than the requests of passes 48 / 49 (a pass or more old),
-                // and the output stores are issued after it, so it never waits for a store.  sc1: the counter is coherent across
-                // the XCDs' L2s, so correctness does not rest on workgroup l really running on XCD l % 8 (only locality does).
-                if (lane_e == 0) {
-                    uint32_t t = 1, zero = 0;
-                    asm volatile("s_nop 7\n\tglobal_atomic_add %0, %1, %0, %2 sc0 sc1\n\ts_waitcnt vmcnt(0)" : "+v"(t) : "v"(zero), "s"(sched + xcd) : "memory");
-                    __hip_atomic_store(&sched[N_XCD + blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            store_tiles_p<TX, NT16>(acc, out + (size_t)tc.img * out_img_bytes, out_img_bytes, om, OW, OH, tc.Y0, tc.X0, w, lane_e & 15,
-                                    lane_e >> 4, false, 0, 0, act_floor, 0u);
-        }
-        if (!has_next) break;
-        item = next;
-        next = __builtin_amdgcn_readfirstlane(sched ? item_end : item + stride);   // with tickets: known once the mailbox has been read (pass 8)
-        tiles_done = __builtin_amdgcn_readfirstlane(tiles_done + 1);
-        tc = tn;
-        set_poff(tc, 3, 4, true);
-        ctx.ring_sw ^= (uint32_t)(4 * TB);   // 100 K-steps = 4 mod 8: the ring halves swap names
-        init_acc();
-    }
-    wait_vmcnt<0>();   // the wrapped tail of the prefetch (weights, out-of-range plane pieces) must land before exit
-#ifdef SICN_STAMP
-    if (g_sicn_stamp && lane == 0) {
-        unsigned long long *o = g_sicn_stamp + ((size_t)blockIdx.x * 4 + w) * 8;
-        o[0] = __builtin_amdgcn_s_memtime() - pp_t0;          // shader cycles over all tiles of this workgroup
-        o[1] = __builtin_amdgcn_s_memrealtime() - pp_r0;      // the same span in 100 MHz ticks
-        o[2] = (unsigned long long)pp_tiles;
-        o[5] = pp_t0;
-        o[6] = __builtin_amdgcn_s_getreg(4 | (31 << 11));    // HW_REG_HW_ID
-        o[7] = __builtin_amdgcn_s_getreg(20 | (31 << 11));   // HW_REG_XCC_ID
-    }
-#endif
-}
-
 // ---- launchers ---------------------------------------------------------------------------------------------------------
 // NT16 < NTF: output-channel split — blockIdx.y = which NT16 * 16 channels a workgroup computes.  Used on grids smaller
 // than the chip (fewer than two workgroups per CU): the tile count cannot grow, the channel dimension can; each workgroup
@@ -897,39 +625,6 @@ bool pipelined_supported(const LayerGeom &g, int tx)
     const bool io = (g.CIN == 128 || g.CIN == 192) && (g.COUT == 128 || g.COUT == 192) && !(g.CIN == 192 && g.COUT == 192);
     if (!io) return false;
     return tx == 16 || (g.CIN == 128 && g.COUT == 128);
-}
-
-// conv 128 -> 128 at 8 x 32 tiles with workgroups that walk through many tiles (k_conv_pp)
-bool persistent_supported(const LayerGeom &g, int tx) { return !g.transposed && g.CIN == 128 && g.COUT == 128 && tx == 32; }
-
-hipError_t launch_persistent(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images, hipStream_t stream,
-                             int in_layout, int out_layout, bool relu, int grid_cap)
-{
-    if (!persistent_supported(g, 32)) return hipErrorInvalidValue;
-    if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB || (size_t)g.OH * g.OW * g.COUT >= (size_t)OOB) return hipErrorInvalidValue;
-    constexpr int NQ = 4, NT16 = 8, TX = 32, PF = 8;
-    const int tiles_x = (g.OW + TX - 1) / TX, tiles_y = (g.OH + TILE_Y - 1) / TILE_Y;
-    const long total = (long)tiles_x * tiles_y * n_images;
-    if (total <= 0 || total > 0x7fffffffL) return hipErrorInvalidValue;
-    constexpr size_t lds = (size_t)4 * Geo<TX>::ALLOC + (size_t)PF * WTile<NT16>::TB;
-    static_assert(lds <= 80 * 1024, "two workgroups per CU");
-    const uint32_t flags = (relu ? ACT_FLOOR_RELU : ACT_FLOOR_RAW) |
-                           (nt_store_wanted((size_t)g.OH * g.OW * g.COUT * n_images) ? ACT_NT_STORE : 0u);
-    const long cap = grid_cap > 0 ? std::max(N_XCD, grid_cap / N_XCD * N_XCD) : 2 * 256;            // two residents per CU
-    const unsigned grid = (unsigned)std::min<long>(cap, (total + N_XCD - 1) / N_XCD * N_XCD);       // a multiple of 8
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_pp<NQ, NT16, TX, PF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    uint32_t *sched = nullptr;
-    if (w.d_sched && grid + N_XCD <= (unsigned)SCHED_WORDS) {
-        const uint32_t slot = __atomic_fetch_add(const_cast<uint32_t *>(&w.sched_next), 1u, __ATOMIC_RELAXED) % SCHED_SLOTS;
-        sched = w.d_sched + (size_t)slot * SCHED_WORDS;
-        e = hipMemsetAsync(sched, 0, N_XCD * sizeof(uint32_t), stream);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL((k_conv_pp<NQ, NT16, TX, PF>), dim3(grid), dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias, g.IW, g.IH, g.OW,
-                       g.OH, tiles_x, tiles_x * tiles_y, n_images, in_layout, out_layout, flags, sched);
-    return hipGetLastError();
 }
 
 hipError_t launch_pipelined(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images, hipStream_t stream,

@@ -2,6 +2,7 @@
 // reference's FixedPointWeights tile format, kernel dispatch, layer chains with caller-provided
 // workspace, per-layer hipEvent timing.  Host code only; kernels live in k_*.hip.
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -35,6 +36,21 @@ const sicn_options &default_options()
         d.split_n = env_int("SICN_SPLIT_N");
         d.wave_tile = env_int("SICN_WAVE_TILE");
         d.prefetch = env_int("SICN_PREFETCH");
+        // the same range checks a caller's struct gets (resolve_options): an out-of-range variable is ignored, loudly, once
+        auto bad = [](const char *name, int32_t &v) {
+            fprintf(stderr, "libsicn: ignoring out-of-range %s=%d\n", name, (int)v);
+            v = 0;
+        };
+        if (d.mfma_shape != 0 && d.mfma_shape != 16 && d.mfma_shape != 32) bad("SICN_MFMA_SHAPE", d.mfma_shape);
+#ifndef SICN_ALT_KERNELS
+        if (d.mfma_shape == 32) bad("SICN_MFMA_SHAPE", d.mfma_shape);
+#endif
+        if (d.tile_x != 0 && d.tile_x != 16 && d.tile_x != 32) bad("SICN_TILE_X", d.tile_x);
+        if (d.strip_chunks < 0) bad("SICN_STRIP_CHUNKS", d.strip_chunks);
+        if (d.no_phase_layout < 0 || d.no_phase_layout > 2) bad("SICN_NO_PHASE_LAYOUT", d.no_phase_layout);
+        if (d.split_n < 0 || d.split_n > 4) bad("SICN_SPLIT_N", d.split_n);
+        if (d.wave_tile != 0 && d.wave_tile != 64 && d.wave_tile != 128) bad("SICN_WAVE_TILE", d.wave_tile);
+        if (d.prefetch < 0 || d.prefetch > 3) bad("SICN_PREFETCH", d.prefetch);
         return d;
     }();
     return o;
@@ -57,6 +73,9 @@ static int resolve_options(const sicn_options *in, sicn_options *out)
     std::memcpy(&o, in, (size_t)in->struct_bytes);
     o.struct_bytes = (int32_t)sizeof(sicn_options);
     if (o.mfma_shape != 0 && o.mfma_shape != 16 && o.mfma_shape != 32) return SICN_EINVAL;
+#ifndef SICN_ALT_KERNELS
+    if (o.mfma_shape == 32) return SICN_EINVAL;   // the 32x32x32 family lives in the ALT build only (libsicn_alt.so)
+#endif
     if (o.tile_x != 0 && o.tile_x != 16 && o.tile_x != 32) return SICN_EINVAL;
     if (o.strip_chunks < 0 || o.no_phase_layout < 0 || o.no_phase_layout > 2) return SICN_EINVAL;
     if (o.split_n < 0 || o.split_n > 4) return SICN_EINVAL;
@@ -72,6 +91,15 @@ extern "C" void sicn_options_init(sicn_options *opt)
 }
 
 extern "C" int sicn_version(void) { return 1000 * 0 + 1; }
+
+extern "C" int sicn_has_alt_kernels(void)
+{
+#ifdef SICN_ALT_KERNELS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 extern "C" const char *sicn_strerror(int code)
 {
@@ -153,7 +181,6 @@ extern "C" void sicn_weights_free(sicn_weights *w)
     if (w->d_w_mfma) (void)hipFree(w->d_w_mfma);
     if (w->d_w_mfma16) (void)hipFree(w->d_w_mfma16);
     if (w->d_w_mfma16x) (void)hipFree(w->d_w_mfma16x);
-    if (w->d_sched) (void)hipFree(w->d_sched);
     if (w->d_w_l0) (void)hipFree(w->d_w_l0);
     if (w->d_w_l7) (void)hipFree(w->d_w_l7);
     delete w;
@@ -206,12 +233,14 @@ extern "C" int sicn_weights_from_finn_tiles(const sicn_layer_desc *d, const void
     }
     try {
         if (ok && mfma_supported(cin, cout, d->transposed)) {
-            if (mfma32_supported(cin, cout, d->transposed)) {   // second implementation (sicn_options.mfma_shape = 32)
+#ifdef SICN_ALT_KERNELS
+            if (mfma32_supported(cin, cout, d->transposed)) {   // second implementation (sicn_options.mfma_shape = 32), ALT build only
                 std::vector<int8_t> s(mfma_stream_bytes(cin, cout));
                 pack_mfma_stream(w_okc.data(), cin, cout, d->transposed, s.data());
                 w->mfma_steps = mfma_stream_steps(cin);
                 ok = upload(s.data(), s.size(), &w->d_w_mfma);
             }
+#endif
             if (ok) {
                 std::vector<int8_t> s16(mfma16_stream_bytes(cin, cout));
                 pack_mfma16_stream(w_okc.data(), cin, cout, d->transposed, s16.data());
@@ -221,10 +250,6 @@ extern "C" int sicn_weights_from_finn_tiles(const sicn_layer_desc *d, const void
                 std::vector<int8_t> sx(mfma16x_deconv_stream_bytes(cin, cout));
                 pack_mfma16x_deconv_stream(w_okc.data(), cin, cout, sx.data());
                 ok = upload(sx.data(), sx.size(), &w->d_w_mfma16x);
-            }
-            if (ok && !d->transposed && cin == 128 && cout == 128) {   // persistent conv kernel: its tile scheduler's counters
-                ok = hipMalloc((void **)&w->d_sched, (size_t)SCHED_SLOTS * SCHED_WORDS * 4) == hipSuccess &&
-                     hipMemset(w->d_sched, 0, (size_t)SCHED_SLOTS * SCHED_WORDS * 4) == hipSuccess;
             }
         }
         if (ok && !d->transposed && cin == 3 && cout % 32 == 0) {
@@ -295,9 +320,13 @@ static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint
     case KK_MFMA_DECONV:
         // MFMA shape: 16x16x64 by default (higher sustained clock, k_mfma16.hip); mfma_shape = 32 selects
         // the 32x32x32 kernels of k_mfma.hip (a second implementation kept under test; reference shapes, ReLU only)
-        e = (o.mfma_shape == 32 && relu && mfma32_supported(d->IFM_CH, d->OFM_CH, d->transposed))
-                ? launch_mfma(g, *w, in, out, n_images, stream, in_layout, out_layout)
-                : launch_mfma16(g, *w, in, out, n_images, stream, in_layout, out_layout, o, relu);
+#ifdef SICN_ALT_KERNELS
+        if (o.mfma_shape == 32 && relu && mfma32_supported(d->IFM_CH, d->OFM_CH, d->transposed)) {
+            e = launch_mfma(g, *w, in, out, n_images, stream, in_layout, out_layout);
+            break;
+        }
+#endif
+        e = launch_mfma16(g, *w, in, out, n_images, stream, in_layout, out_layout, o, relu);
         break;
     default: e = launch_generic(g, *w, in, out, n_images, stream, relu); break;
     }

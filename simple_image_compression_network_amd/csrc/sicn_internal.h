@@ -47,13 +47,7 @@ struct sicn_weights {
     // layer-0 (RGB -> cout) and layer-7 (cin -> RGB) layouts, or nullptr
     int8_t *d_w_l0;
     int8_t *d_w_l7;
-    // tile scheduler of the persistent conv kernel (k_conv_pp): SCHED_SLOTS blocks of {8 per-XCD counters, one mailbox per
-    // workgroup}; every launch takes the next block (so launches in flight on different streams do not share counters) and
-    // zeroes its counters on its stream.  nullptr where the persistent kernel does not serve the shape.
-    uint32_t *d_sched;
-    uint32_t sched_next;   // host-side, advanced with an atomic add
 };
-constexpr int SCHED_SLOTS = 16, SCHED_WORDS = 1024;
 
 namespace sicn {
 
@@ -83,9 +77,6 @@ hipError_t launch_wide(const LayerGeom &g, const sicn_weights &w, const uint8_t 
                        int in_layout, int out_layout, bool relu, int grid_cap);
 // k_mfma16p.hip: the software-pipelined conv / deconv kernels (tile_x = 16 | 32)
 bool pipelined_supported(const LayerGeom &g, int tile_x);
-bool persistent_supported(const LayerGeom &g, int tile_x);
-hipError_t launch_persistent(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images, hipStream_t stream,
-                             int in_layout, int out_layout, bool relu, int grid_cap);
 hipError_t launch_pipelined(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
                             hipStream_t stream, int in_layout, int out_layout, bool relu, int tile_x, bool split_channels);
 hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,

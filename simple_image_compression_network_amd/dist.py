@@ -18,7 +18,8 @@ from typing import Callable, Dict, List, Sequence
 
 import numpy as np
 
-__all__ = ["shard_indices", "checksum", "run_sharded", "broadcast_params", "band_plan", "forward_banded", "BAND_HALO"]
+__all__ = ["shard_indices", "checksum", "checksum_t", "run_sharded", "run_sharded_tensors", "broadcast_params", "band_plan",
+           "forward_banded", "forward_banded_tensors", "BandedNet", "BAND_HALO"]
 
 
 def shard_indices(n_images: int, rank: int, world: int) -> List[int]:
@@ -174,3 +175,121 @@ def forward_banded(compute: Callable[[np.ndarray], Sequence[np.ndarray]], image:
         dist.all_gather(gathered, mine_t, group=group)
         outs.append(np.concatenate([g.cpu().numpy()[:rows[b]] for b, g in enumerate(gathered)]))
     return outs[0], outs[1]
+
+
+# ---- the same two axes on DEVICE tensors: nothing crosses PCIe ---------------------------------------------
+def checksum_t(t):
+    """Order-sensitive checksum of a byte tensor computed where the tensor lives (two modular sums, Fletcher style); returns a
+    0-d int64 tensor on t's device.  Same value on CPU and GPU for the same bytes."""
+    import torch
+    v = t.reshape(-1).to(torch.int64)
+    idx = torch.arange(1, v.numel() + 1, device=v.device, dtype=torch.int64) % 65521
+    return (v.sum() % 4294967291) * 65536 + ((v * idx).sum() % 65521)
+
+
+def run_sharded_tensors(n_images: int, make_batch, compute, group=None):
+    """`run_sharded` without the host hop: `make_batch(indices)` returns this rank's images as ONE tensor [n][H][W][3] on the
+    compute device, `compute` maps it to (recon, latent) tensors on that device, the per-image checksums are taken on the
+    device (`checksum_t`) and the table {global image index: [recon, latent]} is all-gathered on the process group's device
+    (RCCL with backend nccl).  Returns the table as a dict on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    mine = shard_indices(n_images, rank, world)
+    per_rank = (n_images + world - 1) // world
+    backend = dist.get_backend(group) if world > 1 else None
+    if mine:
+        batch = make_batch(mine)
+        recon, latent = compute(batch)
+        rows = [torch.stack([torch.tensor(i, dtype=torch.int64, device=recon.device), checksum_t(recon[k]), checksum_t(latent[k])])
+                for k, i in enumerate(mine)]
+        table = torch.stack(rows)
+        cdev = table.device if backend in (None, "nccl") else torch.device("cpu")
+        table = table.to(cdev)
+    else:
+        cdev = (torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu"))
+        table = torch.empty((0, 3), dtype=torch.int64, device=cdev)
+    pad = torch.full((per_rank - table.shape[0], 3), -1, dtype=torch.int64, device=table.device)
+    table = torch.cat([table, pad])
+    if world == 1:
+        gathered = table
+    else:
+        gathered = torch.empty((world * per_rank, 3), dtype=torch.int64, device=table.device)
+        dist.all_gather_into_tensor(gathered, table, group=group)
+    out: Dict[int, List[int]] = {}
+    for idx, a, b in gathered.cpu().tolist():
+        if idx >= 0:
+            out[int(idx)] = [int(a), int(b)]
+    if sorted(out) != list(range(n_images)):
+        raise RuntimeError("sharding lost or duplicated images")
+    return out
+
+
+def forward_banded_tensors(compute, image, n_bands: int = 0, group=None):
+    """`forward_banded` on tensors: `image` [H][W][3] uint8 on the compute device (the same bytes on every rank), `compute` maps a
+    band tensor [h][W][3] to (recon [16 ceil(h/16)][W'][3], latent [ceil(h/16)][..][192]) tensors on that device.  Rank r
+    computes band r; ONE all_gather_into_tensor per output moves the kept rows (padded to the tallest band) between the
+    devices — with backend nccl straight from and to GPU memory over xGMI.  Returns (reconstruction, latent) of the whole
+    image on every rank, byte-identical to one call on the whole image."""
+    import torch
+    import torch.distributed as dist
+
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if distributed:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        n_bands = world
+    else:
+        rank, world = 0, 1
+        if n_bands <= 0:
+            raise ValueError("n_bands must be given without a process group")
+    H = image.shape[0]
+    plan = band_plan(H, n_bands)
+    out_rows = 16 * ((H + 15) // 16)
+
+    def one(b):
+        i0, i1, k0, k1 = plan[b]
+        recon, latent = compute(image[i0:i1])                # a row range of a row-major tensor is contiguous: no copy
+        r1 = (out_rows if b == n_bands - 1 else k1) - i0     # the last band also owns the rows the rounding adds
+        return recon[k0 - i0:r1], latent[(k0 - i0) // 16:(r1 + 15) // 16]
+
+    if not distributed:
+        parts = [one(b) for b in range(n_bands)]
+        return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+    mine = one(rank)
+    on_cpu = dist.get_backend(group) != "nccl"
+    outs = []
+    for part, unit in ((mine[0], 1), (mine[1], 16)):
+        rows = [((out_rows if b == n_bands - 1 else plan[b][3]) - plan[b][2]) for b in range(n_bands)]
+        rows = [(r + unit - 1) // unit for r in rows]
+        tallest = max(rows)
+        send = torch.zeros((tallest,) + tuple(part.shape[1:]), dtype=torch.uint8, device=part.device)
+        send[:part.shape[0]] = part
+        if on_cpu:
+            send = send.cpu()
+        recv = torch.empty((world * tallest,) + tuple(part.shape[1:]), dtype=torch.uint8, device=send.device)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        outs.append(torch.cat([recv[b * tallest:b * tallest + rows[b]] for b in range(n_bands)]).to(part.device))
+    return outs[0], outs[1]
+
+
+class BandedNet:
+    """ONE image of width x height over the ranks of the process group by horizontal bands: rank r owns an EightLayersNet of its
+    band's height (the HIP path) and `forward(image)` returns the whole reconstruction [1][16 ceil(H/16)][W'][3] on every rank's
+    device, byte-identical to the one-GPU result; only the kept rows cross xGMI (one RCCL all-gather)."""
+
+    def __init__(self, width: int, height: int, world: int, rank: int, params=None, device=None, group=None):
+        from . import api
+        self.group, self.world, self.rank, self.height = group, world, rank, height
+        i0, i1, _, _ = band_plan(height, world)[rank]
+        self.net = api.EightLayersNet(width, i1 - i0, params=params, device=device)
+
+    def forward(self, image, want_latent: bool = False):
+        def compute(band):
+            rec, lat = self.net.forward(band[None], want_latent=True)
+            return rec[0], lat[0]
+        rec, lat = forward_banded_tensors(compute, image[0], group=self.group)
+        return (rec[None], lat[None]) if want_latent else rec[None]

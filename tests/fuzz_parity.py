@@ -45,8 +45,8 @@ for case in range(args.cases):
         env["tile_x"] = int(rng.choice([16, 32]))
     if rng.random() < 0.3:
         env["split_n"] = int(rng.choice([1, 2, 4]))
-    if rng.random() < 0.4:       # the persistent conv kernel (only conv 128 -> 128 at 8 x 32 tiles takes it; others ignore the request)
-        env["prefetch"] = 3
+    if rng.random() < 0.4:       # the wide persistent kernels (only conv / deconv 128 -> 128 take them; others ignore the request)
+        env["wave_tile"] = 128
         env["tile_x"] = 32
         env["persistent_grid"] = int(rng.choice([8, 16, 64, 0]))
     W = rng.integers(-8, 8, (cout, 5, 5, cin)).astype(np.int8)
@@ -81,7 +81,7 @@ for case in range(args.chains):
     if rng.random() < 0.3:
         env["split_n"] = int(rng.choice([1, 2, 4]))
     if rng.random() < 0.4:
-        env["prefetch"] = 3
+        env["wave_tile"] = 128
         env["tile_x"] = 32
         env["persistent_grid"] = int(rng.choice([8, 16, 64, 0]))
     w, h, n = int(rng.integers(1, 26)) * 16, int(rng.integers(1, 20)) * 16, int(rng.integers(1, 3))

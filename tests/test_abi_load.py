@@ -79,7 +79,8 @@ def test_options_defaults_and_validation_without_gpu():
     assert (o.force_generic, o.strip_chunks, o.no_phase_layout) == (0, 0, 0)
     d = REFERENCE_DESCS[1].to_c()
     out = ctypes.c_void_p()
-    for field, bad in (("mfma_shape", 8), ("tile_x", 24), ("strip_chunks", -1), ("no_phase_layout", 3), ("split_n", 7),
+    assert L.sicn_has_alt_kernels() == 0       # the product build: the alternate kernel families are in libsicn_alt.so only
+    for field, bad in (("mfma_shape", 8), ("mfma_shape", 32), ("tile_x", 24), ("strip_chunks", -1), ("no_phase_layout", 3), ("split_n", 7),
                        ("struct_bytes", 4), ("struct_bytes", 4096)):
         o = _lib.make_options()
         setattr(o, field, bad)

@@ -158,3 +158,74 @@ def test_two_ranks_gloo_banded_image():
     recon, latent = _oracle_band(img)
     for _, cr, cl, sr, sl in results:
         assert (cr, cl, sr, sl) == (checksum(recon), checksum(latent), recon.shape, latent.shape)
+
+
+# ---- the tensor forms (device-resident in production; CPU tensors + gloo here) ------------------------------------------------
+from simple_image_compression_network_amd.dist import checksum_t, forward_banded_tensors, run_sharded_tensors  # noqa: E402
+
+
+def _oracle_band_t(band_t):
+    import torch
+    recon, latent = _oracle_band(band_t.numpy())
+    return torch.from_numpy(np.ascontiguousarray(recon)), torch.from_numpy(np.ascontiguousarray(latent))
+
+
+def _oracle_compute_t(batch_t):
+    import torch
+    recon, latent = _oracle_compute(batch_t.numpy())
+    return torch.from_numpy(np.ascontiguousarray(recon)), torch.from_numpy(np.ascontiguousarray(latent))
+
+
+def _make_batch_t(indices):
+    import torch
+    return torch.from_numpy(np.stack([_make_image(i) for i in indices]))
+
+
+def test_tensor_forms_single_process():
+    import torch
+    img = np.random.default_rng(11).integers(0, 256, (BH, BW, 3), dtype=np.uint8)
+    whole_recon, whole_latent = _oracle_band(img)
+    recon, latent = forward_banded_tensors(_oracle_band_t, torch.from_numpy(img), n_bands=3)
+    assert np.array_equal(recon.numpy(), whole_recon) and np.array_equal(latent.numpy(), whole_latent)
+    table = run_sharded_tensors(N, _make_batch_t, _oracle_compute_t)
+    recon_all, latent_all = _oracle_compute(np.stack([_make_image(i) for i in range(N)]))
+    for i in range(N):
+        assert table[i] == [int(checksum_t(torch.from_numpy(recon_all[i]))), int(checksum_t(torch.from_numpy(latent_all[i])))]
+    a = torch.arange(1000, dtype=torch.uint8)
+    assert int(checksum_t(a)) != int(checksum_t(a.flip(0)))       # order-sensitive
+
+
+def _tensor_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        img = torch.from_numpy(np.random.default_rng(11).integers(0, 256, (BH, BW, 3), dtype=np.uint8))
+        recon, latent = forward_banded_tensors(_oracle_band_t, img)
+        q.put((rank, checksum(recon.numpy()), checksum(latent.numpy()), run_sharded_tensors(N, _make_batch_t, _oracle_compute_t)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_tensor_forms():
+    """world size 2: the band split and the image sharding on tensors (one all_gather_into_tensor each), against one process."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tensor_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    img = np.random.default_rng(11).integers(0, 256, (BH, BW, 3), dtype=np.uint8)
+    recon, latent = _oracle_band(img)
+    single = run_sharded_tensors(N, _make_batch_t, _oracle_compute_t)
+    for _, cr, cl, table in results:
+        assert (cr, cl) == (checksum(recon), checksum(latent)) and table == single

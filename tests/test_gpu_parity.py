@@ -115,18 +115,22 @@ def test_strip_kernels_long_strips(api, case, chunks):
 MFMA_CASES = [c for c in SPECIAL if c[0] != 3 and c[1] != 3]
 
 
-@pytest.mark.parametrize("case", MFMA_CASES)
-def test_32x32x32_kernels_match_oracle(api, case):
-    """k_mfma.hip (v_mfma_i32_32x32x32_i8) is kept as a second implementation of L1-L6, selected per call
-    by sicn_options.mfma_shape = 32: it must stay bit-exact too, standalone and inside a chain (internal layouts)."""
-    rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + 5)
-    d = _mk_desc(*case)
-    W, b, words = _rand_params(rng, d)
-    x = rng.integers(0, 128, (2,) + d.in_shape, dtype=np.uint8)
-    got = _run_layer(api, d, words, b, x, mfma_shape=32)
-    ref_fn = sicn_ref.deconv522_ref if d.transposed else sicn_ref.conv2d_ref
-    for i in range(2):
-        assert np.array_equal(got[i], ref_fn(x[i], W, b))
+def test_alt_build_32x32x32_kernels(api):
+    """k_mfma.hip (v_mfma_i32_32x32x32_i8), round 1's kernel family, is a second implementation of L1-L6 that lives in the ALT
+    build only (make ALT=1 -> libsicn_alt.so; the product library rejects mfma_shape = 32).  It must stay bit-exact: the check
+    runs in a process of its own that loads the ALT library (tests/alt_kernels_check.py: every MFMA shape standalone against
+    the oracle and a whole chain against the Appendix-A hashes)."""
+    import os
+    alt = ROOT / "simple_image_compression_network_amd" / "libsicn_alt.so"
+    assert alt.exists(), "build() makes libsicn_alt.so"
+    assert api._lib.lib().sicn_has_alt_kernels() == 0
+    o = api._lib.make_options(mfma_shape=32)
+    d = _mk_desc(128, 128, 8, 16, 8, 8, 0).to_c()
+    assert api._lib.lib().sicn_conv2d_opt(ctypes.byref(d), None, None, None, 1, ctypes.byref(o), None) == -22
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "alt_kernels_check.py")], capture_output=True, text=True,
+                       env=dict(os.environ, SICN_LIB=str(alt)), timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "alt kernels ok" in r.stdout
 
 
 @pytest.mark.parametrize("prefetch", [1, 2])
@@ -183,16 +187,16 @@ PERSISTENT_CASES = [(128, 128, 8, 16, 130, 66, 0), (128, 128, 8, 16, 66, 18, 0),
 @pytest.mark.parametrize("grid", [8, 16, 0])
 @pytest.mark.parametrize("case", PERSISTENT_CASES)
 def test_persistent_conv_matches_oracle(api, case, grid):
-    """k_conv_pp: conv 128 -> 128 by workgroups that walk through MANY tiles (the plane refresh of a tile's last channel group
-    fetches the next tile, the weight ring wraps, the first fragments of a tile are fetched by the last pass of the one
-    before).  Forced (prefetch = 3) with 8 / 16 workgroups so that every one of them gets several tiles of these small
-    inputs — across image boundaries (n = 3), ragged right / bottom tiles, single-tile images — and with the default grid."""
+    """conv 128 -> 128 by PERSISTENT workgroups that walk through many tiles (k_conv_x: the plane refresh of a tile's last
+    passes fetches the next tile, the weight ring wraps, the accumulator hand-over sits in the next tile's first pass).  Forced
+    (wave_tile = 128) with 8 / 16 workgroups so that every one of them gets several tiles of these small inputs — across image
+    boundaries (n = 3), ragged right / bottom tiles, single-tile images — and with the default grid."""
     rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + grid)
     d = _mk_desc(*case)
     W, b, words = _rand_params(rng, d)
     x = rng.integers(0, 128, (3,) + d.in_shape, dtype=np.uint8)
     x[0].reshape(-1)[::7] |= 0x80
-    got = _run_layer(api, d, words, b, x, tile_x=32, prefetch=3, persistent_grid=grid)
+    got = _run_layer(api, d, words, b, x, wave_tile=128, persistent_grid=grid)
     for i in range(3):
         ref = sicn_ref.conv2d_ref(x[i], W, b)
         assert np.array_equal(got[i], ref), (i, np.count_nonzero(got[i] != ref))
@@ -201,7 +205,7 @@ def test_persistent_conv_matches_oracle(api, case, grid):
 @pytest.mark.parametrize("grid", [8, 40])
 def test_persistent_conv_in_chain(api, grid):
     xin = _dev(np.stack([_input("rng768"), _input("ones768")]))
-    net = api.EightLayersNet(768, 512, options={"tile_x": 32, "prefetch": 3, "persistent_grid": grid})
+    net = api.EightLayersNet(768, 512, options={"wave_tile": 128, "persistent_grid": grid})
     out, latent = net.forward(xin)
     torch.cuda.synchronize()
     for i, name in enumerate(("rng768", "ones768")):
@@ -301,15 +305,6 @@ def test_both_tile_widths_in_chain(api, tile_x):
     torch.cuda.synchronize()
     assert _sha(out[0].cpu().numpy()) == HASHES["layers"]["rng768"][7]
     assert _sha(latent[0].cpu().numpy()) == HASHES["layers"]["rng768"][3]
-
-
-def test_32x32x32_kernels_in_chain(api):
-    xin = _dev(_input("rng256")[None])
-    net = api.EightLayersNet(256, 256, options={"mfma_shape": 32})
-    out, latent = net.forward(xin)
-    torch.cuda.synchronize()
-    assert _sha(out[0].cpu().numpy()) == HASHES["layers"]["rng256"][7]
-    assert _sha(latent[0].cpu().numpy()) == HASHES["layers"]["rng256"][3]
 
 
 def test_specialised_and_generic_kernels_agree(api):
@@ -647,12 +642,12 @@ def test_capture_helper_replays(api):
     assert _sha(lat[0].cpu().numpy()) == HASHES["layers"]["rng768"][3]
 
 
-def test_persistent_conv_graph_replay_and_two_streams(api):
-    """k_conv_pp draws its tiles from ticket counters in a block of device memory that belongs to the layer's weights; every
-    launch takes the next block (16 of them) and zeroes its counters on its own stream.  So (a) a captured forward pass —
-    whose launches are frozen on one block each, with the memset as a graph node — must replay correctly any number of times,
-    and (b) two streams driving ONE net at the same time must not disturb each other's counters."""
-    opts = {"tile_x": 32, "prefetch": 3, "persistent_grid": 16}
+def test_persistent_kernels_graph_replay_and_two_streams(api):
+    """The wide persistent kernels keep no scheduler state (tiles are dealt statically), so a weights handle is immutable:
+    (a) a captured forward pass replays correctly any number of times, (b) a graph replaying on one stream while a second
+    stream makes 64 eager launches through the SAME sicn_weights disturbs neither (round 2's k_conv_pp
+    shared 16 ticket blocks per handle and could not promise this)."""
+    opts = {"wave_tile": 128, "persistent_grid": 16}
     net = api.EightLayersNet(768, 512, options=opts)
     x = _dev(np.stack([_input("rng768"), _input("ones768")]))
     out = torch.empty((2, 512, 768, 3), dtype=torch.uint8, device="cuda")
@@ -665,17 +660,20 @@ def test_persistent_conv_graph_replay_and_two_streams(api):
     for i, name in enumerate(("rng768", "ones768")):
         assert _sha(out[i].cpu().numpy()) == HASHES["layers"][name][7]
         assert _sha(lat[i].cpu().numpy()) == HASHES["layers"][name][3]
-    # two streams through the SAME device weights (and therefore the same scheduler blocks), each with its own workspace
+    # the graph on one stream, 64 eager forwards through the SAME device weights on another, interleaved
     net2 = api.EightLayersNet(768, 512, options=opts, shared_weights=net.weights)
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    outs = [torch.empty_like(out) for _ in range(2)]
-    for it in range(12):
-        with torch.cuda.stream(s1):
-            net.forward(x, outs[0], want_latent=False, stream=s1)
-        with torch.cuda.stream(s2):
-            net2.forward(x, outs[1], want_latent=False, stream=s2)
+    out2 = torch.empty_like(out)
     torch.cuda.synchronize()
-    for o in outs:
+    for it in range(64):
+        with torch.cuda.stream(s1):
+            if it % 4 == 0:
+                out.zero_()
+            g.replay()
+        with torch.cuda.stream(s2):
+            net2.forward(x, out2, want_latent=False, stream=s2)
+    torch.cuda.synchronize()
+    for o in (out, out2):
         assert _sha(o[0].cpu().numpy()) == HASHES["layers"]["rng768"][7]
         assert _sha(o[1].cpu().numpy()) == HASHES["layers"]["ones768"][7]
 
