@@ -328,34 +328,53 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
         }
         step += NQ;
     };
-    int par = 0;
 #ifdef SICN_STAMP
     dst[1] = __builtin_amdgcn_s_memtime();
 #endif
+    // With an odd number of passes per tap (192 input channels) the two pixel buffers swap roles from tap to tap.  The parity
+    // is kept STATIC — taps are walked in pairs, and a phase's first parity is a constant of the phase (9 / 6 / 6 / 4 taps) —
+    // because a run-time parity made hipcc reconcile the two register assignments with v_mov copies right in front of and
+    // right behind the asm MFMAs, inside their hazard windows (tools/isa_hazards.py, rules A and D; round 3).
 #pragma unroll
     for (int ph = 0; ph < 4; ph++) {
         const int py = ph >> 1, px = ph & 1;
         const int nkx = 3 - px, ntap = (3 - py) * nkx;
-#pragma unroll 1
-        for (int t = 0; t < ntap; t++) {
+        const int par0 = (PPT % 2) ? (ph == 0 ? 0 : ph == 1 ? (9 & 1) : ph == 2 ? ((9 + 6) & 1) : ((9 + 6 + 6) & 1)) : 0;
+        auto offsets = [&](int t, uint32_t &toff, uint32_t &toff_next) {
             const int iy = t / nkx, ix = t - iy * nkx;
-            const uint32_t toff = (uint32_t)(((iy + py) * PX + ix + px) * 32);
-            uint32_t toff_next;   // the tap after this one (the next phase's first tap at the end of a phase)
-            if (t + 1 < ntap) {
+            toff = (uint32_t)(((iy + py) * PX + ix + px) * 32);
+            if (t + 1 < ntap) {   // the tap after this one (the next phase's first tap at the end of a phase)
                 const int t1 = t + 1, iy1 = t1 / nkx, ix1 = t1 - iy1 * nkx;
                 toff_next = (uint32_t)(((iy1 + py) * PX + ix1 + px) * 32);
             } else {
                 const int ph1 = (ph + 1) & 3;
                 toff_next = (uint32_t)(((ph1 >> 1) * PX + (ph1 & 1)) * 32);
             }
-            if constexpr (PPT % 2 == 0) {
-                tap(std::integral_constant<int, 0>{}, ph, t, toff, toff_next);   // an even number of passes: the parity never changes
+        };
+        auto one = [&](auto par_tag, int t) {
+            uint32_t toff, toff_next;
+            offsets(t, toff, toff_next);
+            tap(par_tag, ph, t, toff, toff_next);
+        };
+        if constexpr (PPT % 2 == 0) {
+#pragma unroll 1
+            for (int t = 0; t < ntap; t++) one(std::integral_constant<int, 0>{}, t);   // an even number of passes: the parity never changes
+        } else {
+            int t = 0;
+            if (par0 == 0) {
+#pragma unroll 1
+                for (; t + 1 < ntap; t += 2) {
+                    one(std::integral_constant<int, 0>{}, t);
+                    one(std::integral_constant<int, 1>{}, t + 1);
+                }
+                if (t < ntap) one(std::integral_constant<int, 0>{}, t);
             } else {
-                if (par == 0)
-                    tap(std::integral_constant<int, 0>{}, ph, t, toff, toff_next);
-                else
-                    tap(std::integral_constant<int, 1>{}, ph, t, toff, toff_next);
-                par ^= 1;
+#pragma unroll 1
+                for (; t + 1 < ntap; t += 2) {
+                    one(std::integral_constant<int, 1>{}, t);
+                    one(std::integral_constant<int, 0>{}, t + 1);
+                }
+                if (t < ntap) one(std::integral_constant<int, 1>{}, t);
             }
         }
 #ifdef SICN_STAMP

@@ -87,3 +87,17 @@ def test_options_defaults_and_validation_without_gpu():
         assert L.sicn_conv2d_opt(ctypes.byref(d), None, None, None, 1, ctypes.byref(o), None) == -22
         assert L.sicn_net_create_opt(ctypes.byref(d), ctypes.byref(out), 1, ctypes.byref(o), ctypes.byref(out)) == -22
     assert not hasattr(L, "sicn_set_force_generic")
+
+
+def test_isa_hazard_checker_flags_the_known_bugs():
+    """tools/isa_hazards.py (run over the asm kernels' ISA by build()): its self-test holds the two round-2 bugs and the round-3
+    one as ISA snippets — a VALU-unpacked bias read as an asm MFMA's C operand, an asm atomic whose address SGPRs come from a
+    v_readlane, an accumulator read out right behind the asm MFMA that wrote it — plus an LDS fragment used without a wait;
+    every one must be flagged and a clean accumulate chain must pass."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "isa_hazards.py"), "--selftest"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("ok ") == 5 and "FAIL" not in r.stdout
