@@ -130,7 +130,9 @@ class LatentCoder:
 
     def decode(self, out_latents, slots=None, valid=None, stream=None):
         """slots (default: self.slots) -> out_latents [n][h][w][c], self.dec_status. `valid`: device int32 [n][2] status
-        array whose `.bytes` bound each slot (default: the encoder's); pass False to trust the whole slot. Enqueue only."""
+        array whose `.bytes` bound each slot.  Default: this object's own encoder status when it decodes its OWN slots; with
+        external `slots` the whole slot is trusted (the header's payload field is validated anyway) unless the caller passes
+        the status array that travelled with them.  Pass False to trust the whole slot in every case. Enqueue only."""
         import torch
         n, h, w, c = self.shape
         slots = self.slots if slots is None else slots
@@ -138,7 +140,8 @@ class LatentCoder:
             raise TypeError(f"out_latents must be a contiguous CUDA uint8 tensor of shape {self.shape}")
         if not (slots.is_cuda and slots.dtype == torch.uint8 and slots.is_contiguous() and tuple(slots.shape) == (n, self.slot)):
             raise TypeError("slots must be a contiguous CUDA uint8 tensor [n][slot_bytes]")
-        vptr = None if valid is False else ctypes.c_void_p((self.enc_status if valid is None else valid).data_ptr())
+        own = slots is self.slots
+        vptr = None if (valid is False or (valid is None and not own)) else ctypes.c_void_p((self.enc_status if valid is None else valid).data_ptr())
         _lib.check(_lib.lib().sicn_codec_decode_batch_async(
             ctypes.c_void_p(slots.data_ptr()), self.slot, vptr, n, w, h, c, ctypes.c_void_p(out_latents.data_ptr()), h * w * c,
             ctypes.c_void_p(self.dec_status.data_ptr()), ctypes.c_void_p(self.ws.data_ptr()), self.ws.numel(), _stream_ptr(stream)),
@@ -197,7 +200,8 @@ class ContextCoder:
         self._check(scales, "scales")
         n, h, w, c = self.shape
         slots = self.slots if slots is None else slots
-        vptr = None if valid is False else ctypes.c_void_p((self.enc_status if valid is None else valid).data_ptr())
+        own = slots is self.slots     # external containers: trust the slot unless their status array came along (see LatentCoder.decode)
+        vptr = None if (valid is False or (valid is None and not own)) else ctypes.c_void_p((self.enc_status if valid is None else valid).data_ptr())
         _lib.check(_lib.lib().sicn_codec_ctx_decode_batch_async(
             ctypes.c_void_p(slots.data_ptr()), self.slot, vptr, ctypes.c_void_p(scales.data_ptr()), n, w, h, c,
             ctypes.c_void_p(out_latents.data_ptr()), ctypes.c_void_p(self.dec_status.data_ptr()),

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -375,7 +376,8 @@ struct sicn_net {
     mutable std::atomic<bool> profile{false};
     mutable std::atomic<int> ev_next{0};       // slots handed out since the last reset (may run past EV_RING)
     std::vector<hipEvent_t> ev_begin, ev_end;  // [EV_RING], created by sicn_net_profile
-    mutable std::vector<int> ev_layer;         // [EV_RING] layer recorded in the slot
+    mutable std::unique_ptr<std::atomic<int>[]> ev_layer;   // [EV_RING] layer recorded in the slot (release on write, acquire on read:
+                                                            // sicn_net_layer_ms may run beside forward calls on other threads)
 };
 
 static size_t out_bytes(const sicn_layer_desc &d) { return (size_t)d.OFM_COL * d.OFM_ROW * d.OFM_CH; }
@@ -481,7 +483,7 @@ extern "C" int sicn_net_forward(const sicn_net *net, int first, int last, const 
                                    : 0;
         const int slot = slot0 >= 0 ? slot0 + (l - first) : -1;
         if (slot >= 0) {
-            net->ev_layer[slot] = -1;   // becomes l once both events are recorded
+            net->ev_layer[slot].store(-1, std::memory_order_relaxed);   // becomes l once both events are recorded
             if (hipEventRecord(net->ev_begin[slot], stream) != hipSuccess) return SICN_ENODEV;
         }
         int rc = run_layer(&net->descs[l], net->weights[l], cur, dst, n_images, stream, -1, net->opt, cur_layout, out_layout,
@@ -489,7 +491,7 @@ extern "C" int sicn_net_forward(const sicn_net *net, int first, int last, const 
         if (rc) return rc;
         if (slot >= 0) {
             if (hipEventRecord(net->ev_end[slot], stream) != hipSuccess) return SICN_ENODEV;
-            net->ev_layer[slot] = l;
+            net->ev_layer[slot].store(l, std::memory_order_release);
         }
         if (l == tap_layer && tap_out != dst) {
             if (hipMemcpyAsync(tap_out, dst, out_bytes(net->descs[l]) * (size_t)n_images, hipMemcpyDeviceToDevice,
@@ -522,7 +524,8 @@ extern "C" int sicn_net_profile(sicn_net *net, int enable)
         try {
             a.reserve(n);
             b.reserve(n);
-            net->ev_layer.assign(n, -1);
+            net->ev_layer.reset(new std::atomic<int>[n]);
+            for (size_t i = 0; i < n; i++) net->ev_layer[i].store(-1, std::memory_order_relaxed);
         } catch (const std::bad_alloc &) { return SICN_ENOMEM; }
         bool ok = true;
         for (size_t i = 0; i < n && ok; i++) {
@@ -554,7 +557,7 @@ extern "C" int sicn_net_layer_ms(sicn_net *net, int reset, float *ms_sum, int *l
     if (used > sicn_net::EV_RING) used = sicn_net::EV_RING;
     if (net->ev_begin.empty()) used = 0;
     for (int i = 0; i < used; i++) {
-        const int l = net->ev_layer[i];
+        const int l = net->ev_layer[i].load(std::memory_order_acquire);
         if (l < 0 || (size_t)l >= n_layers) continue;   // reserved by a call that failed before recording
         if (hipEventSynchronize(net->ev_end[i]) != hipSuccess) return SICN_ENODEV;
         float ms = 0.f;
@@ -563,7 +566,7 @@ extern "C" int sicn_net_layer_ms(sicn_net *net, int reset, float *ms_sum, int *l
         launches[l]++;
     }
     if (reset) {
-        for (int i = 0; i < used; i++) net->ev_layer[i] = -1;
+        for (int i = 0; i < used; i++) net->ev_layer[i].store(-1, std::memory_order_relaxed);
         net->ev_next.store(0, std::memory_order_release);
     }
     return SICN_OK;

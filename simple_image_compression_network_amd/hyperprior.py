@@ -127,10 +127,12 @@ class HyperpriorCodec:
         self.y_coder.encode(self.y, self._scale_map(self.z_hat))
         return self.z_coder.slots, self.y_coder.slots
 
-    def decode(self, out, z_slots=None, y_slots=None):
-        """containers -> reconstruction `out` [n][H'][W'][3]. Enqueue only."""
-        self.z_coder.decode(self.z_hat, slots=z_slots)
-        self.y_coder.decode(self.y_hat, self._scale_map(self.z_hat), slots=y_slots)
+    def decode(self, out, z_slots=None, y_slots=None, z_valid=None, y_valid=None):
+        """containers -> reconstruction `out` [n][H'][W'][3]. Enqueue only.  z_valid / y_valid: the encoder's status arrays
+        (device int32 [n][2], `.bytes` bounds each container) when they travelled with external slots; without them an
+        external slot is trusted as a whole (the container header is validated either way)."""
+        self.z_coder.decode(self.z_hat, slots=z_slots, valid=z_valid)
+        self.y_coder.decode(self.y_hat, self._scale_map(self.z_hat), slots=y_slots, valid=y_valid)
         self.main.synthesis(self.y_hat, out)
         return out
 
