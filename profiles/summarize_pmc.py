@@ -20,7 +20,7 @@ tag, out = sys.argv[1], Path(sys.argv[2])
 
 
 def short(n):
-    return n.replace("void sicn::", "").replace("sicn::", "").split("(")[0]
+    return n.replace("void sicn::", "").replace("sicn::", "").replace("xw::", "").split("(")[0]
 
 
 def is_layer_kernel(name):
@@ -39,6 +39,8 @@ def by_layer(rows, key):
         names = {short(r["Kernel_Name"]) for r in rs}
         if len(names) != 1:
             raise SystemExit(f"layer {l}: dispatch order does not repeat with period 8: {names}")
+    if not out[0] or not short(out[0][0]["Kernel_Name"]).startswith("k_l0") or not short(out[7][0]["Kernel_Name"]).startswith("k_l7"):
+        raise SystemExit("the dispatch sequence does not start with layer 0 / end with layer 7: " + str({l: short(rs[0]["Kernel_Name"]) for l, rs in out.items()}))
     return out
 
 
