@@ -58,7 +58,10 @@ def pack_words(W_okkc, simd, pe):
 SMALL = [  # case id, Cin, Cout, SIMD, PE, W, H, transposed
     (0, 3, 128, 3, 8, 24, 16, 0), (1, 3, 128, 3, 8, 21, 17, 0), (2, 128, 128, 8, 16, 20, 16, 0),
     (3, 128, 192, 8, 24, 19, 17, 0), (4, 192, 128, 12, 16, 6, 4, 1), (5, 128, 128, 8, 16, 5, 5, 1),
-    (6, 128, 3, 8, 3, 9, 6, 1)]
+    (6, 128, 3, 8, 3, 9, 6, 1),
+    # folds the net does NOT use (the compiled reference template depends on the dimensions only, so the case ids of rows 2, 5
+    # and 3 serve): the tile walk (nf, sf, simd nibble order) is exercised against reference-made bytes at other SIMD / PE too
+    (2, 128, 128, 4, 32, 20, 16, 0), (5, 128, 128, 16, 8, 5, 5, 1), (3, 128, 192, 2, 96, 19, 17, 0)]
 
 
 def main():

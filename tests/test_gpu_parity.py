@@ -591,7 +591,7 @@ def test_reference_compiled_vectors_on_gpu(api):
         got = _run_layer(api, d, words, bias, x[None])
         assert np.array_equal(got[0], y), d
         n += 1
-    assert n == 7
+    assert n == 10
 
 
 def test_forward_is_graph_capturable(api):

@@ -204,7 +204,7 @@ def test_every_oracle_form_matches_reference_compiled_vectors():
         for form in ("dataflow", "dataflow_im2col", "naive", "direct"):
             assert np.array_equal(c_oracle.run_layer(d, words, bias, x, form), y), (d, form)
         n += 1
-    assert n == 7
+    assert n == 10
 
 
 def test_ref_conv_padded_map_forms_agree():
