@@ -417,10 +417,9 @@ static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint
             // (measured, r02: at 192 - 255 tiles the split is a wash or a loss; at <= 72 it takes 20 - 35 % off the layer)
             const long tiles16 = (long)((MW + 15) / 16) * ((MH + TILE_Y - 1) / TILE_Y) * n_images;
             const bool split = tx == 16 && (o.split_n > 1 || (o.split_n == 0 && tiles16 <= 128));
-            // deconv 192 -> 128 on a full grid (>= 1024 tiles): three passes per tap keep the pipelined form from double-buffering its weight
-            // fragments, and there the plain kernel is 7 % faster (layer 4 at 8 x 4K: 0.159 against 0.171 ms); with the
-            // output-channel split (small grids) the pipelined one wins
-            if (!(o.prefetch == 0 && g.transposed && g.CIN == 192 && !split && tiles16 >= 1024))
+            // (round 2 sent the deconv 192 -> 128 on full grids back to the plain kernel: the pipelined one was 7 % slower there.  The
+            // reason was the v_mov copies hipcc made for its run-time buffer parity — right around the asm MFMAs, where
+            // tools/isa_hazards.py found them; with the parity static the pipelined form is 17 % FASTER: layer 4 0.158 -> 0.131 ms.)
                 return launch_pipelined(g, w, in, out, n_images, stream, in_layout, out_layout, relu, tx, split);
         }
     }

@@ -45,11 +45,17 @@ constexpr int NPASS = 50;                                                 // pas
 typedef __attribute__((address_space(3))) uint8_t lds_u8;   // LDS pointers stay 32-bit (a generic pointer costs a null check per cast)
 
 #define SICN_MFMA_A(ACC, A, B) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
-// C = 0: the accumulator starts here.  The operand is tied all the same ("+a"): the new value must live in the AGPRs of the old
+// C = bias: the accumulator starts here.  The D operand is tied all the same ("+a"): the new value must live in the AGPRs of the old
 // one, and whatever still wants the old value (the hand-over's reads) is thereby ordered in front of this statement.  (With an
 // output-only operand hipcc gave the new values other registers and moved them through VGPRs with v_accvgpr_read right behind the
 // MFMA — inside the MFMA's latency, where the hazard recogniser does not look for an asm statement: wrong bytes.)
-#define SICN_MFMA_A0(ACC, A, B) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "+a"(ACC) : "v"(A), "v"(B))
+#define SICN_MFMA_AC(ACC, A, B, C) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %3" : "+a"(ACC) : "v"(A), "v"(B), "a"(C))
+// accumulator tiles j = 7 (8 of the 64) live in VGPRs: that leaves 28 AGPRs for the bias of tiles j = 0 .. 6, which the first pass
+// of a tile / phase takes as its C operand (C and D of an MFMA must sit in the same register file), and those 8 tiles need no
+// v_accvgpr_read at the hand-over
+#define SICN_MFMA_V(ACC, A, B) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
+#define SICN_MFMA_VC(ACC, A, B, C) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %3" : "+v"(ACC) : "v"(A), "v"(B), "v"(C))
+constexpr int JV = 7;   // accumulator tiles j >= JV live in VGPRs
 
 template <int OFF>
 __device__ __forceinline__ v4i lds_read(uint32_t addr)
@@ -74,33 +80,25 @@ struct HandX {
     uint32_t floor2;             // pack4's floor (ReLU / identity)
 };
 
-// relu7((v + bias) mod 256) for four accumulators: pack4_relu7 of k_common.hpp with the bias byte added while the byte sits in
-// the high half of a 16-bit lane (no carry can reach it from below: the low half is 0)
-__device__ __forceinline__ uint32_t pack4_bias(const v4i &a, uint32_t bias_ab, uint32_t bias_cd, uint32_t floor2)
-{
-    const uint32_t ab = __builtin_amdgcn_perm((uint32_t)a[1], (uint32_t)a[0], 0x040c000cu);
-    const uint32_t cd = __builtin_amdgcn_perm((uint32_t)a[3], (uint32_t)a[2], 0x040c000cu);
-    typedef unsigned short v2u __attribute__((ext_vector_type(2)));
-    const v2u sab = __builtin_bit_cast(v2u, ab) + __builtin_bit_cast(v2u, bias_ab);
-    const v2u scd = __builtin_bit_cast(v2u, cd) + __builtin_bit_cast(v2u, bias_cd);
-    const v2s z = __builtin_bit_cast(v2s, floor2);
-    const v2s mab = __builtin_elementwise_max(__builtin_bit_cast(v2s, sab), z);
-    const v2s mcd = __builtin_elementwise_max(__builtin_bit_cast(v2s, scd), z);
-    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, mcd), __builtin_bit_cast(uint32_t, mab), 0x07050301u);
-}
-
-// this lane's bias bytes in the form pack4_bias adds them: channel 64 J + 16 g + 4 d + r is register r of accumulator tile
-// 4 J + d; bias[J][d][0] = {b(r = 0), b(r = 1)} and [1] = {b(2), b(3)}, each byte in the high half of its 16-bit lane
-__device__ __forceinline__ void load_bias_x(uint32_t (&b)[2][4][2], const int8_t *bias, int g)
+// this lane's bias as the first pass's C operand: register r of accumulator tile j is channel 64 (j >> 2) + 16 g + 4 (j & 3) + r.
+// (Until the accumulators moved: added in the pack, v_pk_add_u16 on the byte in the high half of a 16-bit lane — 128 VALU
+// instructions per hand-over at 3.2 issue cycles each.)
+struct BiasX {
+    v4i c[8];
+};
+__device__ __forceinline__ void load_bias_x(BiasX &b, const int8_t *bias, int g)
 {
 #pragma unroll
     for (int J = 0; J < 2; J++) {
         const v4i b4 = *(const v4i *)(bias + 64 * J + 16 * g);
 #pragma unroll
         for (int d = 0; d < 4; d++) {
-            const uint32_t x = (uint32_t)b4[d];
-            b[J][d][0] = ((x & 0xffu) << 8) | ((x & 0xff00u) << 16);
-            b[J][d][1] = ((x & 0xff0000u) >> 8) | (x & 0xff000000u);
+#pragma unroll
+            for (int r = 0; r < 4; r++) b.c[4 * J + d][r] = (int)(int8_t)((uint32_t)b4[d] >> (8 * r));
+            if (4 * J + d < JV)
+                asm volatile("" : "+a"(b.c[4 * J + d]));
+            else
+                asm volatile("" : "+v"(b.c[4 * J + d]));
         }
     }
 }
@@ -120,7 +118,7 @@ __device__ __forceinline__ void load_bias_x(uint32_t (&b)[2][4][2], const int8_t
 constexpr int NOW = 8, NHELD = NOW < 8 ? 2 * (8 - NOW) : 1;
 template <int KIND, int VM, int EXTRA, bool NT, int SIDX, class Rd, class Dma>
 __device__ __forceinline__ void pass_x(v4i (&acc)[8][8], const v4i (&pc)[8], const v4i (&wc)[8], Rd rd, Dma dma, bool stores, const HandX &h,
-                                       const uint32_t (&bias)[2][4][2], v4i (&held)[NHELD])
+                                       const BiasX &bias, v4i (&held)[NHELD])
 {
     if constexpr (KIND == 0) {
         int issued = 0;
@@ -129,7 +127,10 @@ __device__ __forceinline__ void pass_x(v4i (&acc)[8][8], const v4i (&pc)[8], con
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int m = j * 8 + i;
-                SICN_MFMA_A(acc[i][j], wc[j], pc[i]);
+                if (j < JV)
+                    SICN_MFMA_A(acc[i][j], wc[j], pc[i]);
+                else
+                    SICN_MFMA_V(acc[i][j], wc[j], pc[i]);
                 // the 16 reads of the next pass: one behind every third MFMA, the last one behind MFMA 47
                 if (m % 3 == 2 && issued < 16) {
                     switch (issued) {
@@ -167,17 +168,31 @@ __device__ __forceinline__ void pass_x(v4i (&acc)[8][8], const v4i (&pc)[8], con
 #pragma unroll
                 for (int d = 0; d < 4; d++) old[d] = acc[i][4 * J + d];   // read out (v_accvgpr_read) in front of the tied MFMA below
 #endif
-#pragma unroll
-                for (int d = 0; d < 4; d++) SICN_MFMA_A0(acc[i][4 * J + d], wc[4 * J + d], pc[i]);
                 v4i v;
+                // a tile that lives in VGPRs is packed straight from its registers, BEFORE the tied MFMA overwrites them (packed
+                // behind it, hipcc would copy the four registers first)
+#pragma unroll
+                for (int d = 0; d < 4; d++)
+                    if (4 * J + d >= JV) {
+                        v[d] = (int)pack4_relu7(old[d][0], old[d][1], old[d][2], old[d][3], h.floor2);
+                        asm volatile("" : "+v"(v[d]));
+                    }
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    if (4 * J + d < JV)
+                        SICN_MFMA_AC(acc[i][4 * J + d], wc[4 * J + d], pc[i], bias.c[4 * J + d]);
+                    else
+                        SICN_MFMA_VC(acc[i][4 * J + d], wc[4 * J + d], pc[i], bias.c[4 * J + d]);
+                }
 #if defined(SICN_XW_NOPACK)    // timing experiments (wrong results): what of the hand-over costs what
 #pragma unroll
                 for (int d = 0; d < 4; d++) v[d] = old[d][0] ^ old[d][1] ^ old[d][2] ^ old[d][3];
 #elif defined(SICN_XW_NOREAD)
-                v = v4i{(int)bias[J][0][0], (int)bias[J][1][0], (int)bias[J][2][0], (int)bias[J][3][0]};
+                v = v4i{1, 2, 3, 4};
 #else
 #pragma unroll
-                for (int d = 0; d < 4; d++) v[d] = (int)pack4_bias(old[d], bias[J][d][0], bias[J][d][1], h.floor2);
+                for (int d = 0; d < 4; d++)
+                    if (4 * J + d < JV) v[d] = (int)pack4_relu7(old[d][0], old[d][1], old[d][2], old[d][3], h.floor2);
 #endif
 #ifdef SICN_XW_NOSTORE
                 asm volatile("" ::"v"(v));
@@ -377,7 +392,7 @@ __device__ __forceinline__ void set_poff_x(uint32_t (&poff)[4][SLOTS], const Ten
 template <int T, int KIND, bool NT>
 __device__ __forceinline__ void conv_pass_x(v4i (&acc)[8][8], const v4i (&pc)[8], const v4i (&wc)[8], v4i (&pn)[8], v4i (&wn)[8],
                                             const ConvXCtx &c, const uint32_t (&poff)[4][SLOTS], bool stores, const HandX &h,
-                                            const uint32_t (&bias)[2][4][2])
+                                            const BiasX &bias)
 {
     constexpr int P = T % 25, WIN = T / 25;
     // ---- fragments of the next pass (T + 1, wrapping into the next tile: same offsets, the ring does not care) --------------
@@ -427,7 +442,7 @@ __device__ __forceinline__ void conv_pass_x(v4i (&acc)[8][8], const v4i (&pc)[8]
 
 template <int T, int END, bool NT>
 __device__ __forceinline__ void conv_passes_x(v4i (&acc)[8][8], v4i (&pa)[8], v4i (&wa)[8], v4i (&pb)[8], v4i (&wb)[8], const ConvXCtx &c,
-                                              const uint32_t (&poff)[4][SLOTS], bool stores, const HandX &h, const uint32_t (&bias)[2][4][2])
+                                              const uint32_t (&poff)[4][SLOTS], bool stores, const HandX &h, const BiasX &bias)
 {
     if constexpr ((T & 1) == 0)
         conv_pass_x<T, 0, NT>(acc, pa, wa, pb, wb, c, poff, stores, h, bias);
@@ -478,7 +493,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                  in_img_bytes,
                  im.grp,
                  hi};
-    uint32_t bias[2][4][2];
+    BiasX bias;
     load_bias_x(bias, bias_g, g);
     // ---- prologue of the FIRST tile only: what the previous window's NEXT0 requests would have brought (planes 0, 1 and
     // ---- slots 0 .. 2 of plane 2 of group 0) + the weight tiles of passes 0 .. 4 -------------------------------------------
@@ -511,15 +526,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     h.ro = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, 0, 0x00020000);
 #pragma unroll
     for (int c = 0; c < 8; c++) h.off[c] = OOB;
-    // the first pass of the first tile: on zeroed accumulators, nothing to hand over
+    // the first pass of the first tile: accumulators start at the bias, nothing to hand over
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            acc[i][j] = v4i{0, 0, 0, 0};
-            asm volatile("" : "+a"(acc[i][j]));
+            acc[i][j] = bias.c[j];
+            if (j < JV)
+                asm volatile("" : "+a"(acc[i][j]));
+            else
+                asm volatile("" : "+v"(acc[i][j]));
         }
-    asm volatile("s_nop 3" ::: "memory");   // v_accvgpr_write -> asm MFMA reading it as SrcC
+    asm volatile("s_nop 3" ::: "memory");   // v_accvgpr_write / v_mov -> asm MFMA reading it as SrcC
     conv_pass_x<0, 0, NT>(acc, pa, wa, pb, wb, ctx, poff, false, h, bias);
 #ifdef SICN_STAMP
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
@@ -700,7 +718,7 @@ __device__ __forceinline__ void set_dpoff_x(uint32_t (&poff)[SLOTS], const Tenso
 template <int T, int KIND, bool NT>
 __device__ __forceinline__ void deconv_pass_x(v4i (&acc)[8][8], const v4i (&pc)[8], const v4i (&wc)[8], v4i (&pn)[8], v4i (&wn)[8],
                                               const DeconvXCtx &c, const uint32_t (&poff_cur)[SLOTS], const uint32_t (&poff_next)[SLOTS],
-                                              bool stores, const HandX &h, const uint32_t (&bias)[2][4][2], v4i (&held)[NHELD])
+                                              bool stores, const HandX &h, const BiasX &bias, v4i (&held)[NHELD])
 {
     constexpr int TN = (T + 1) % NPASS;
     constexpr DPass N = dpass(TN);
@@ -782,7 +800,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                    0u,
                    (uint32_t)PAIRBUF,
                    (uint32_t)(2 * PAIRBUF)};
-    uint32_t bias[2][4][2];
+    BiasX bias;
     load_bias_x(bias, bias_g, g);
     // ---- prologue of the FIRST tile only: its pair 0, pieces 0 .. 4 of its pair 1, the weight tiles of passes 0 .. 4 --------
     {
@@ -827,10 +845,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            acc[i][j] = v4i{0, 0, 0, 0};
-            asm volatile("" : "+a"(acc[i][j]));
+            acc[i][j] = bias.c[j];
+            if (j < JV)
+                asm volatile("" : "+a"(acc[i][j]));
+            else
+                asm volatile("" : "+v"(acc[i][j]));
         }
-    asm volatile("s_nop 3" ::: "memory");   // v_accvgpr_write -> asm MFMA reading it as SrcC
+    asm volatile("s_nop 3" ::: "memory");   // v_accvgpr_write / v_mov -> asm MFMA reading it as SrcC
     deconv_pass_x<0, 0, NT>(acc, pa, wa, pb, wb, ctx, poff_cur, poff_next, false, h, bias, held);
 #ifdef SICN_STAMP
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
