@@ -77,8 +77,21 @@ struct HandX {
     uint32_t off[8];             // per pixel fragment: byte offset of this lane's 16 bytes of channel group g >> 1 (OOB outside)
     uint32_t soff;               // scalar part of the offset (deconv: the phase's parity plane / pixel)
     uint32_t grp2;               // 2 channel groups = 64 channels on: the second store of a pixel fragment
-    uint32_t floor2;             // pack4's floor (ReLU / identity)
+    uint32_t floor2;             // the pack's floor as a signed value: 0 (ReLU) / -128 (identity)
 };
+
+// relu7(v mod 256) of four accumulators packed into one dword by four SDWA instructions: max(sign-extended byte 0 of the
+// accumulator, floor) written to byte k of the result (floor 0 = the reference's ReLU, -128 = identity: the lane before the ReLU
+// for the GDN extension).  One instruction per accumulator register; pack4_relu7 (perm, perm, max, max, perm) takes 5 per 4.
+__device__ __forceinline__ uint32_t pack4_sdwa(const v4i &a, int floor32)
+{
+    uint32_t out;
+    asm("v_max_i32_sdwa %0, sext(%1), %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(out) : "v"(a[0]), "s"(floor32));
+    asm("v_max_i32_sdwa %0, sext(%1), %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:DWORD" : "+v"(out) : "v"(a[1]), "s"(floor32));
+    asm("v_max_i32_sdwa %0, sext(%1), %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:DWORD" : "+v"(out) : "v"(a[2]), "s"(floor32));
+    asm("v_max_i32_sdwa %0, sext(%1), %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:DWORD" : "+v"(out) : "v"(a[3]), "s"(floor32));
+    return out;
+}
 
 // this lane's bias as the first pass's C operand: register r of accumulator tile j is channel 64 (j >> 2) + 16 g + 4 (j & 3) + r.
 // (Until the accumulators moved: added in the pack, v_pk_add_u16 on the byte in the high half of a 16-bit lane — 128 VALU
@@ -174,7 +187,7 @@ __device__ __forceinline__ void pass_x(v4i (&acc)[8][8], const v4i (&pc)[8], con
 #pragma unroll
                 for (int d = 0; d < 4; d++)
                     if (4 * J + d >= JV) {
-                        v[d] = (int)pack4_relu7(old[d][0], old[d][1], old[d][2], old[d][3], h.floor2);
+                        v[d] = (int)pack4_sdwa(old[d], (int)h.floor2);
                         asm volatile("" : "+v"(v[d]));
                     }
 #pragma unroll
@@ -192,7 +205,7 @@ __device__ __forceinline__ void pass_x(v4i (&acc)[8][8], const v4i (&pc)[8], con
 #else
 #pragma unroll
                 for (int d = 0; d < 4; d++)
-                    if (4 * J + d < JV) v[d] = (int)pack4_relu7(old[d][0], old[d][1], old[d][2], old[d][3], h.floor2);
+                    if (4 * J + d < JV) v[d] = (int)pack4_sdwa(old[d], (int)h.floor2);
 #endif
 #ifdef SICN_XW_NOSTORE
                 asm volatile("" ::"v"(v));
@@ -522,7 +535,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     HandX h;
     h.soff = 0u;
     h.grp2 = 2u * om.grp;
-    h.floor2 = act_floor & ACT_FLOOR_MASK;
+    h.floor2 = (act_floor & ACT_FLOOR_MASK) == ACT_FLOOR_RELU ? 0u : (uint32_t)-128;
     h.ro = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, 0, 0x00020000);
 #pragma unroll
     for (int c = 0; c < 8; c++) h.off[c] = OOB;
@@ -829,7 +842,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     HandX h;
     h.soff = 0u;
     h.grp2 = 2u * om.grp;
-    h.floor2 = act_floor & ACT_FLOOR_MASK;
+    h.floor2 = (act_floor & ACT_FLOOR_MASK) == ACT_FLOOR_RELU ? 0u : (uint32_t)-128;
     h.ro = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, 0, 0x00020000);
 #pragma unroll
     for (int c = 0; c < 8; c++) h.off[c] = OOB;
