@@ -122,16 +122,12 @@ __device__ __forceinline__ void load_bias_x(BiasX &b, const int8_t *bias, int g)
 //   stored (hand-over of the tile / phase that has just ended) right before the MFMA that overwrites it.
 //   VM: requests that may stay in flight at the barrier; EXTRA: plus the hand-over's stores while `stores` (they are younger than
 //   what the wait is after during the first FLIGHT passes behind a hand-over: counted, not waited for)
-//   SIDX >= 0 (deferred hand-over, the deconv): a hand-over stores its first NOW pixel fragments at once and keeps the packed
-//   results of the others in `held`; the passes behind it store them two at a time — fragment SIDX in pass SIDX behind the
-//   hand-over — where a store's ~80 issue cycles disappear between MFMAs (16 stores inside the hand-over pass cost it 1260 cycles;
-//   in-kernel stamps).  NOT IN USE (NOW = 8: every fragment is stored at once): holding 6 or 8 fragments (48 / 64 VGPRs) on top of
-//   the two fragment sets made hipcc spill 100 - 950 registers in the deconv kernel, and a scratch access is a vmcnt(0) wait in the
-//   middle of the DMA pipeline.  The mechanism stays for a register-leaner pass.  SIDX < 0 and KIND 2: all stored at once (the conv).
-constexpr int NOW = 8, NHELD = NOW < 8 ? 2 * (8 - NOW) : 1;
-template <int KIND, int VM, int EXTRA, bool NT, int SIDX, class Rd, class Dma>
+//   (Tried and removed: keeping the packed results in VGPRs and storing them two per pass behind the hand-over.  Once the
+//   bias registers were gone it fitted — 204 - 220 VGPRs, no scratch — and the hand-over pass did get 400 cycles shorter, but the
+//   deconv tile got 1300 cycles LONGER: a store costs its ~80 issue cycles wherever it sits.  The cost model is additive.)
+template <int KIND, int VM, int EXTRA, bool NT, class Rd, class Dma>
 __device__ __forceinline__ void pass_x(v4i (&acc)[8][8], const v4i (&pc)[8], const v4i (&wc)[8], Rd rd, Dma dma, bool stores, const HandX &h,
-                                       const BiasX &bias, v4i (&held)[NHELD])
+                                       const BiasX &bias)
 {
     if constexpr (KIND == 0) {
         int issued = 0;
@@ -158,12 +154,6 @@ __device__ __forceinline__ void pass_x(v4i (&acc)[8][8], const v4i (&pc)[8], con
                 if (m == 20) dma(std::integral_constant<int, 1>{});
                 if (m == 36) dma(std::integral_constant<int, 2>{});
                 if (m == 52) dma(std::integral_constant<int, 3>{});
-                if constexpr (SIDX >= NOW) {   // this pass's two deferred stores
-                    if (m == 12 && stores)
-                        __builtin_amdgcn_raw_buffer_store_b128(held[2 * (SIDX - NOW)], h.ro, h.off[SIDX], h.soff, NT ? 2 : 0);
-                    if (m == 44 && stores)
-                        __builtin_amdgcn_raw_buffer_store_b128(held[2 * (SIDX - NOW) + 1], h.ro, h.off[SIDX], h.soff + h.grp2, NT ? 2 : 0);
-                }
             }
         }
     } else {
@@ -210,15 +200,7 @@ __device__ __forceinline__ void pass_x(v4i (&acc)[8][8], const v4i (&pc)[8], con
 #ifdef SICN_XW_NOSTORE
                 asm volatile("" ::"v"(v));
 #else
-                if (SIDX >= 0 && k >= 2 * NOW) {
-                    switch (k) {   // constant indices only: a variable one would put `held` into scratch memory
-#define SICN_HK(K) case K: if constexpr (K >= 2 * NOW) held[K - 2 * NOW] = v; break;
-                        SICN_HK(0) SICN_HK(1) SICN_HK(2) SICN_HK(3) SICN_HK(4) SICN_HK(5) SICN_HK(6) SICN_HK(7)
-                        SICN_HK(8) SICN_HK(9) SICN_HK(10) SICN_HK(11) SICN_HK(12) SICN_HK(13) SICN_HK(14) SICN_HK(15)
-#undef SICN_HK
-                    }
-                } else
-                    __builtin_amdgcn_raw_buffer_store_b128(v, h.ro, h.off[i], h.soff + (uint32_t)J * h.grp2, NT ? 2 : 0);
+                __builtin_amdgcn_raw_buffer_store_b128(v, h.ro, h.off[i], h.soff + (uint32_t)J * h.grp2, NT ? 2 : 0);
 #endif
                 switch (k) {
 #define SICN_R(R) case R: rd(std::integral_constant<int, R>{}); break;
@@ -449,8 +431,7 @@ __device__ __forceinline__ void conv_pass_x(v4i (&acc)[8][8], const v4i (&pc)[8]
 #else
     constexpr int VM = in_flight_x(P);
 #endif
-    v4i none[NHELD];
-    pass_x<KIND, VM, (T < FLIGHT ? NSTORE : 0), NT, -1>(acc, pc, wc, rd, dma, stores, h, bias, none);
+    pass_x<KIND, VM, (T < FLIGHT ? NSTORE : 0), NT>(acc, pc, wc, rd, dma, stores, h, bias);
 }
 
 template <int T, int END, bool NT>
@@ -649,22 +630,6 @@ __host__ __device__ constexpr DReq dreq(int T)
     if (T >= 45) return DReq{2, T - 45};
     return DReq{-1, 0};
 }
-// deferred hand-over stores: the pass that starts a phase (a hand-over) and the 7 behind it store one pixel fragment each
-__host__ __device__ constexpr int dstore_idx(int T)
-{
-    const int t = ((T % NPASS) + NPASS) % NPASS;
-    const int start = t >= 42 ? 42 : t >= 30 ? 30 : t >= 18 ? 18 : 0;
-    return t - start < 8 ? t - start : -1;
-}
-__host__ __device__ constexpr int dstores_in_flight(int T)   // stores issued in the last FLIGHT passes
-{
-    int s = 0;
-    for (int i = 0; i < FLIGHT; i++) {
-        const int x = dstore_idx(T - i);
-        s += x == 0 ? 2 * NOW : x >= NOW ? 2 : 0;
-    }
-    return s;
-}
 __host__ __device__ constexpr int drequests(int T) { return 2 + (dreq(((T % NPASS) + NPASS) % NPASS).kind >= 0); }
 __host__ __device__ constexpr int d_in_flight(int T)
 {
@@ -731,7 +696,7 @@ __device__ __forceinline__ void set_dpoff_x(uint32_t (&poff)[SLOTS], const Tenso
 template <int T, int KIND, bool NT>
 __device__ __forceinline__ void deconv_pass_x(v4i (&acc)[8][8], const v4i (&pc)[8], const v4i (&wc)[8], v4i (&pn)[8], v4i (&wn)[8],
                                               const DeconvXCtx &c, const uint32_t (&poff_cur)[SLOTS], const uint32_t (&poff_next)[SLOTS],
-                                              bool stores, const HandX &h, const BiasX &bias, v4i (&held)[NHELD])
+                                              bool stores, const HandX &h, const BiasX &bias)
 {
     constexpr int TN = (T + 1) % NPASS;
     constexpr DPass N = dpass(TN);
@@ -766,9 +731,10 @@ __device__ __forceinline__ void deconv_pass_x(v4i (&acc)[8][8], const v4i (&pc)[
             }
         }
     };
-    // the two deferred stores of each of the last FLIGHT passes are counted, not waited for
-    constexpr int EXTRA = dstores_in_flight(T);
-    pass_x<KIND, d_in_flight(T), EXTRA, NT, dstore_idx(T)>(acc, pc, wc, rd, dma, stores, h, bias, held);
+    // stores of a hand-over are counted, not waited for, during the FLIGHT passes that start with it
+    constexpr bool behind = dphase_start(T) || dphase_start((T + NPASS - 1) % NPASS) || dphase_start((T + NPASS - 2) % NPASS);
+    static_assert(FLIGHT == 3, "`behind` spells out FLIGHT passes");
+    pass_x<KIND, d_in_flight(T), (behind ? NSTORE : 0), NT>(acc, pc, wc, rd, dma, stores, h, bias);
 }
 
 template <bool NT>
@@ -846,9 +812,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     h.ro = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, 0, 0x00020000);
 #pragma unroll
     for (int c = 0; c < 8; c++) h.off[c] = OOB;
-    v4i held[NHELD];   // a hand-over's packed results of pixel fragments NOW .. 7, stored two per pass by the passes behind it
-#pragma unroll
-    for (int k = 0; k < NHELD; k++) held[k] = v4i{0, 0, 0, 0};
     // scalar offset of output phase (py, px): output pixel (2 y + py, 2 x + px) against (2 y, 2 x)
     auto phase_soff = [&](int ph) { return tensor_offset(om, ph >> 1, ph & 1, 0u); };
     int next = item + stride;
@@ -865,7 +828,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 asm volatile("" : "+v"(acc[i][j]));
         }
     asm volatile("s_nop 3" ::: "memory");   // v_accvgpr_write / v_mov -> asm MFMA reading it as SrcC
-    deconv_pass_x<0, 0, NT>(acc, pa, wa, pb, wb, ctx, poff_cur, poff_next, false, h, bias, held);
+    deconv_pass_x<0, 0, NT>(acc, pa, wa, pb, wb, ctx, poff_cur, poff_next, false, h, bias);
 #ifdef SICN_STAMP
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long st_hand = 0;
@@ -883,9 +846,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // passes 1 .. 5; from pass 6 on the patch requests belong to the next tile
 #define SICN_DP(T, ST) \
     if constexpr (((T) & 1) == 0) \
-        deconv_pass_x<T, dphase_start(T) ? 2 : 0, NT>(acc, pa, wa, pb, wb, ctx, poff_cur, poff_next, ST, h, bias, held); \
+        deconv_pass_x<T, dphase_start(T) ? 2 : 0, NT>(acc, pa, wa, pb, wb, ctx, poff_cur, poff_next, ST, h, bias); \
     else \
-        deconv_pass_x<T, dphase_start(T) ? 2 : 0, NT>(acc, pb, wb, pa, wa, ctx, poff_cur, poff_next, ST, h, bias, held);
+        deconv_pass_x<T, dphase_start(T) ? 2 : 0, NT>(acc, pb, wb, pa, wa, ctx, poff_cur, poff_next, ST, h, bias);
         // `stores`: passes 1 .. 7 store the previous tile's last phase (none in the first tile), and a wait counts the stores of
         // the passes up to FLIGHT - 1 back
         SICN_DP(1, stores) SICN_DP(2, stores) SICN_DP(3, stores) SICN_DP(4, stores) SICN_DP(5, stores)
@@ -931,7 +894,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned long long st_p0 = __builtin_amdgcn_s_memtime();
 #endif
         // pass 0 of the next tile with the hand-over of this tile's phase 3 woven in (after the last tile: on a zero-filled patch)
-        deconv_pass_x<0, 2, NT>(acc, pa, wa, pb, wb, ctx, poff_cur, poff_next, true, h, bias, held);
+        deconv_pass_x<0, 2, NT>(acc, pa, wa, pb, wb, ctx, poff_cur, poff_next, true, h, bias);
 #undef SICN_DP
         stores = true;
 #ifdef SICN_STAMP
@@ -959,11 +922,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         o[6] = __builtin_amdgcn_s_getreg(20 | (31 << 11));
     }
 #endif
-    // the last hand-over's fragments NOW .. 7 are still held
-#pragma unroll
-    for (int f = NOW; f < 8; f++)
-#pragma unroll
-        for (int J = 0; J < 2; J++) __builtin_amdgcn_raw_buffer_store_b128(held[2 * (f - NOW) + J], h.ro, h.off[f], h.soff + (uint32_t)J * h.grp2, NT ? 2 : 0);
     wait_vmcnt<0>();
 }
 
