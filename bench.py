@@ -406,19 +406,24 @@ def main():
         sdt = timed(lambda: net.forward(xs, outs_s, lat_s), max(4, args.steps // 2))
         strong = {"value": round(world * per * W * H * max(4, args.steps // 2) / sdt / 1e6, 2), "unit": "Mpixels/s", "scaling": "strong",
                   "images_per_gpu": per, "global_images": world * per, "ms_per_step": round(sdt / max(4, args.steps // 2) * 1e3, 3)}
-        # one 4K image over N ranks by horizontal bands (device-resident, one all-gather of the kept rows)
+        # one image over the N ranks by horizontal bands (device-resident with nccl: one all-gather of the kept rows over xGMI)
+        img = x[:1].clone()
         if args.backend == "nccl":
-            img = x[:1]
             dist.broadcast(img, src=0)
-            bnet = sdist.BandedNet(W, H, world, rank, params=params, device=dev)
-            rec_b = bnet.forward(img)
-            bsteps = max(4, args.steps // 2)
-            bdt = timed(lambda: bnet.forward(img), bsteps)
-            whole = torch.empty((1,) + net.descs[-1].out_shape, dtype=torch.uint8, device=dev)
-            net.forward(img, whole, want_latent=False)
-            banded = {"ms_per_image": round(bdt / bsteps * 1e3, 3), "value": round(W * H * bsteps / bdt / 1e6, 2), "unit": "Mpixels/s",
-                      "bands": world, "equals_one_gpu_bytes": bool(torch.equal(rec_b, whole)),
-                      "note": "latency of ONE 4K image: each rank computes a band with 64 rows of recomputed halo, RCCL all-gather of the kept rows"}
+        else:
+            t = img.cpu()
+            dist.broadcast(t, src=0)
+            img = t.to(dev)
+        bnet = sdist.BandedNet(W, H, world, rank, params=params, device=dev)
+        rec_b = bnet.forward(img)
+        bsteps = max(4, args.steps // 2)
+        bdt = timed(lambda: bnet.forward(img), bsteps)
+        whole = torch.empty((1,) + net.descs[-1].out_shape, dtype=torch.uint8, device=dev)
+        net.forward(img, whole, want_latent=False)
+        torch.cuda.synchronize()
+        banded = {"ms_per_image": round(bdt / bsteps * 1e3, 3), "value": round(W * H * bsteps / bdt / 1e6, 2), "unit": "Mpixels/s",
+                  "bands": world, "equals_one_gpu_bytes": bool(torch.equal(rec_b, whole)),
+                  "note": "latency of ONE image: each rank computes a band with 64 rows of recomputed halo, one all-gather of the kept rows"}
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()

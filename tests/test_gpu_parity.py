@@ -553,6 +553,9 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     assert len(d["rank_checksums"]) == 2 and d["rank_checksums"][0] != d["rank_checksums"][1]
     assert d["output_bit_exact"] is None                 # no golden hashes for this rehearsal size
     assert d["with_coder"]["round_trip_exact"] is True and d["with_coder"]["value"] > 0
+    # the N > 1 secondaries: strong scaling (64 / N images per rank) and one image over the ranks by bands
+    assert d["strong_scaling"]["images_per_gpu"] == 32 and d["strong_scaling"]["value"] > 0
+    assert d["banded"]["bands"] == 2 and d["banded"]["equals_one_gpu_bytes"] is True
 
 
 def test_bench_rccl_code_path_single_rank():
