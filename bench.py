@@ -273,6 +273,17 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def secondary(name, fn):
+        """A secondary measurement must never cost the headline line: an exception is reported in its place (and on stderr).
+        Every rank runs the same secondaries in the same order, so a failure that hits all ranks alike keeps the collectives
+        of `timed` aligned."""
+        try:
+            return fn()
+        except Exception as e:   # noqa: BLE001 - reported, not swallowed
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            return {"error": f"{name}: {type(e).__name__}: {e}"}
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -313,8 +324,7 @@ def main():
     rank_checksums = [int(g[1].item()) for g in gathered]
 
     # ---- secondary: the same batch through the entropy coder ---------------------------------------
-    with_coder = None
-    if not args.no_coder:
+    def coder_leg():
         lat2 = torch.empty_like(latent)
         coder = codec.LatentCoder(B, *net.descs[3].out_shape, image_width=W, image_height=H, device=dev)
 
@@ -330,16 +340,17 @@ def main():
         cdt = timed(coder_step, csteps)
         coder.check()        # device-side verdicts of the last step (checksums of the decoded latents included)
         ok = bool(torch.equal(lat2, latent)) and (zlib.adler32(out.cpu().numpy().reshape(-1)) & 0xFFFFFFFF) == rank_checksums[rank]
-        with_coder = {"value": round(world * B * W * H * csteps / cdt / 1e6, 2), "unit": "Mpixels/s",
+        return {"value": round(world * B * W * H * csteps / cdt / 1e6, 2), "unit": "Mpixels/s",
                       "ms_per_step": round(cdt / csteps * 1e3, 3), "steps": csteps,
                       "bits_per_pixel": round(8.0 * sum(coder.sizes()) / (B * W * H), 4), "round_trip_exact": ok,
                       "path": "analysis (L0-L3) -> sicn_codec_encode_batch_async (rANS-W) -> sicn_codec_decode_batch_async -> "
                               "synthesis (L4-L7), all enqueued on one stream without host synchronisation",
                       "note": "the coder is this project's own (the reference has none); parity unpinned"}
+
+    with_coder = None if args.no_coder else secondary("with_coder", coder_leg)
     # ---- secondary: BASELINE.json configs[4], the hyperprior configuration (GDN / IGDN main transform, hyper stacks,
     # ---- mode-3 coder for the hyper-latent, mode-4 conditional coder for the latent) on the same batch -----------------
-    hyper = None
-    if not args.no_hyperprior:
+    def hyper_leg():
         from simple_image_compression_network_amd.hyperprior import HyperpriorCodec
         hc = HyperpriorCodec(W, H, B, seed=0, device=dev, main_params=params)
         out_h2 = torch.empty_like(out)
@@ -355,7 +366,7 @@ def main():
         hc.check()
         direct = torch.empty_like(out)
         hc.main.forward(x, direct, want_latent=False)      # the same transform without the coders in between
-        hyper = {"value": round(world * B * W * H * hsteps / hdt / 1e6, 2), "unit": "Mpixels/s",
+        return {"value": round(world * B * W * H * hsteps / hdt / 1e6, 2), "unit": "Mpixels/s",
                  "ms_per_step": round(hdt / hsteps * 1e3, 3), "steps": hsteps,
                  "bits_per_pixel": round(8.0 * sum(hc.bytes_per_image()) / (B * W * H), 4),
                  "round_trip_exact": bool(torch.equal(hc.y_hat, hc.y)) and bool(torch.equal(out_h2, direct)),
@@ -363,10 +374,10 @@ def main():
                          "rANS-W(z) -> h_s -> rANS-WC(y) -> g_s (L4-L7, IGDN); one stream, no host synchronisation",
                  "note": "BASELINE.json configs[4]; no reference counterpart (SURVEY.md section 0): parity unpinned, seeded random "
                          "hyper / GDN parameters"}
-        del hc, out_h2, direct
+
+    hyper = None if args.no_hyperprior else secondary("hyperprior", hyper_leg)
     # ---- secondary: the same step with HOST buffers on both sides (pinned memory, upload / compute / download streams) ----
-    pcie = None
-    if not args.no_host_io and rank == 0 and world == 1:
+    def host_io_leg():
         from simple_image_compression_network_amd.host_pipeline import HostPipeline
         hp = HostPipeline(net, B, depth=2, want_latent=True)
         nb = 3                                               # distinct host batches in flight (the data repeats: synthetic)
@@ -386,27 +397,30 @@ def main():
         pdt = time.perf_counter() - t0
         same = all((zlib.adler32(t.numpy().reshape(-1)) & 0xFFFFFFFF) == rank_checksums[rank] for t in h_out)
         step_bytes = x.numel() + out.numel() + latent.numel()
-        pcie = {"value": round(B * W * H * psteps / pdt / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(pdt / psteps * 1e3, 3),
+        return {"value": round(B * W * H * psteps / pdt / 1e6, 2), "unit": "Mpixels/s", "ms_per_step": round(pdt / psteps * 1e3, 3),
                 "steps": psteps, "host_bytes_per_step": int(step_bytes),
                 "pcie_GBs_each_way": round(max(x.numel(), out.numel() + latent.numel()) * psteps / pdt / 1e9, 1),
                 "outputs_equal_resident_run": bool(same),
                 "path": "pinned host batch -> H2D stream -> eight_layers_net on the compute stream -> D2H stream (reconstruction + "
                         "latent), 2 device slots, events between the three streams (host_pipeline.HostPipeline)",
                 "note": "never `value`: the headline is HBM-resident; this is the rate a caller that owns host streams sees"}
-        del hp, h_in, h_out, h_lat
+
+    pcie = secondary("host_io", host_io_leg) if (not args.no_host_io and rank == 0 and world == 1) else None
     # ---- secondaries of the multi-GPU runs (N > 1): strong scaling and the single-image band split ----------------------
-    strong = banded = None
-    if world > 1 and not args.headline_only:
-        from simple_image_compression_network_amd import dist as sdist
+    def strong_leg():
         per = max(1, 64 // world)                      # BASELINE.json configs[3]: 64 images in all, 64 / N per rank
         xs = x[:per] if per <= B else torch.cat([x] * ((per + B - 1) // B))[:per]
         outs_s = torch.empty((per,) + net.descs[-1].out_shape, dtype=torch.uint8, device=dev)
         lat_s = torch.empty((per,) + net.descs[3].out_shape, dtype=torch.uint8, device=dev)
         net.forward(xs, outs_s, lat_s)
-        sdt = timed(lambda: net.forward(xs, outs_s, lat_s), max(4, args.steps // 2))
-        strong = {"value": round(world * per * W * H * max(4, args.steps // 2) / sdt / 1e6, 2), "unit": "Mpixels/s", "scaling": "strong",
-                  "images_per_gpu": per, "global_images": world * per, "ms_per_step": round(sdt / max(4, args.steps // 2) * 1e3, 3)}
+        ssteps = max(4, args.steps // 2)
+        sdt = timed(lambda: net.forward(xs, outs_s, lat_s), ssteps)
+        return {"value": round(world * per * W * H * ssteps / sdt / 1e6, 2), "unit": "Mpixels/s", "scaling": "strong",
+                "images_per_gpu": per, "global_images": world * per, "ms_per_step": round(sdt / ssteps * 1e3, 3)}
+
+    def banded_leg():
         # one image over the N ranks by horizontal bands (device-resident with nccl: one all-gather of the kept rows over xGMI)
+        from simple_image_compression_network_amd import dist as sdist
         img = x[:1].clone()
         if args.backend == "nccl":
             dist.broadcast(img, src=0)
@@ -421,9 +435,14 @@ def main():
         whole = torch.empty((1,) + net.descs[-1].out_shape, dtype=torch.uint8, device=dev)
         net.forward(img, whole, want_latent=False)
         torch.cuda.synchronize()
-        banded = {"ms_per_image": round(bdt / bsteps * 1e3, 3), "value": round(W * H * bsteps / bdt / 1e6, 2), "unit": "Mpixels/s",
-                  "bands": world, "equals_one_gpu_bytes": bool(torch.equal(rec_b, whole)),
-                  "note": "latency of ONE image: each rank computes a band with 64 rows of recomputed halo, one all-gather of the kept rows"}
+        return {"ms_per_image": round(bdt / bsteps * 1e3, 3), "value": round(W * H * bsteps / bdt / 1e6, 2), "unit": "Mpixels/s",
+                "bands": world, "equals_one_gpu_bytes": bool(torch.equal(rec_b, whole)),
+                "note": "latency of ONE image: each rank computes a band with 64 rows of recomputed halo, one all-gather of the kept rows"}
+
+    strong = banded = None
+    if world > 1 and not args.headline_only:
+        strong = secondary("strong_scaling", strong_leg)
+        banded = secondary("banded", banded_leg)
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
@@ -495,7 +514,7 @@ def main():
     if banded is not None:
         res["banded"] = banded
     if not args.no_configs and world == 1:
-        res["configs"] = small_configs(api, codec, dev)
+        res["configs"] = secondary("configs", lambda: small_configs(api, codec, dev))
     if pcie is not None:
         res["host_io"] = pcie
     if with_coder is not None:
@@ -503,7 +522,7 @@ def main():
     if hyper is not None:
         res["hyperprior"] = hyper
     if world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(host[0], args.cpu_sample, lat_h[0], out_h[0])
+        res["cpu_baseline"] = secondary("cpu_baseline", lambda: cpu_baseline(host[0], args.cpu_sample, lat_h[0], out_h[0]))
     if use_dist:
         res["config"]["collectives"] = f"torch.distributed backend {dist.get_backend()} (bookkeeping only: weight broadcast, barrier, MAX of the timed region, checksum all-gather)"
     print(json.dumps(res))

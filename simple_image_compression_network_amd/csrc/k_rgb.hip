@@ -276,6 +276,9 @@ hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
 #ifndef SICN_L7_AUX
 #define SICN_L7_AUX 0
 #endif
+#ifndef SICN_EXP_L7_STORE
+#define SICN_EXP_L7_STORE 0
+#endif
 constexpr int L7_AUX = SICN_L7_AUX;                       // cache policy of the input stream (2 = nt)
 constexpr int L7_PITCH = 36;                             // positions per window row (34 used)
 constexpr int L7_ROWS = 4;                               // input rows per step
@@ -432,11 +435,20 @@ __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ 
                 const int row = idx >= 48 ? 1 : 0, col = idx - 48 * row;
                 const bool ok = idx < 96 && gy < IH;
                 const uint32_t v = *(const uint32_t *)(my_stage + (idx < 96 ? idx : 0) * 4);
-                const uint32_t off = ok ? (uint32_t)(((2 * gy + row) * OW + 2 * X0) * 3 + col * 4) : OOB;
+                uint32_t off = ok ? (uint32_t)(((2 * gy + row) * OW + 2 * X0) * 3 + col * 4) : OOB;
+#if SICN_EXP_L7_STORE == 2   // timing experiment (wrong bytes): the same stores, all into the first 256 KiB (no HBM write traffic)
+                off = ok ? (off & 0x3FFFCu) : OOB;
+#endif
+#if SICN_EXP_L7_STORE != 1   // 1 = timing experiment without the stores
                 __builtin_amdgcn_raw_buffer_store_b32(v, ro, off, 0, 0);
+#endif
             }
             // leave in flight: this step's 2 stores and the AHEAD-1 younger row blocks (5 loads + 2 stores each)
+#if SICN_EXP_L7_STORE == 1
+            wait_vmcnt<5 * (L7_AHEAD - 1)>();
+#else
             wait_vmcnt<2 + 7 * (L7_AHEAD - 1)>();
+#endif
         } else {
 #pragma unroll
             for (int c = 0; c < 2; c++) {

@@ -556,6 +556,7 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     # the N > 1 secondaries: strong scaling (64 / N images per rank) and one image over the ranks by bands
     assert d["strong_scaling"]["images_per_gpu"] == 32 and d["strong_scaling"]["value"] > 0
     assert d["banded"]["bands"] == 2 and d["banded"]["equals_one_gpu_bytes"] is True
+    assert not [k for k, v in d.items() if isinstance(v, dict) and "error" in v], d     # no secondary leg failed
 
 
 def test_bench_rccl_code_path_single_rank():
@@ -574,6 +575,7 @@ def test_bench_rccl_code_path_single_rank():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert "nccl" in d["config"]["collectives"] and d["value"] > 0 and d["with_coder"]["round_trip_exact"] is True
+    assert not [k for k, v in d.items() if isinstance(v, dict) and "error" in v], d
 
 
 def test_committed_small_vectors_on_gpu(api):
