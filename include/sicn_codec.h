@@ -17,7 +17,8 @@
  *   mode 2  rANS     byte-wise rANS, 12-bit static frequencies measured on this latent, independent
  *                    streams of 1024 symbols (one GPU lane per stream), stream offsets by a
  *                    wavefront-level prefix scan
- *   mode 3  rANS-W   the wavefront form (the one to use): streams of 16384 symbols, each coded by one wave
+ *   mode 3  rANS-W   the wavefront form (the one to use): streams of 16384 symbols (or the encoder's choice of a shorter
+ *                    power of two down to 1024: the _sl entry points), each coded by one wave
  *                    whose 64 lanes hold 64 interleaved rANS states sharing one stream of 16-bit words; a
  *                    lane's word position inside a step is a wavefront-level scan (popcount of a ballot).
  *                    Lane l owns 4 consecutive symbols of every 256-symbol block.  Same frequency table as
@@ -48,6 +49,7 @@ extern "C" {
 
 typedef struct sicn_codec_info {
     uint32_t mode, image_width, image_height, lat_w, lat_h, lat_c, n_symbols, n_streams, payload_bytes, adler32;
+    uint32_t stream_symbols; /* header dword 9: symbols per stream (mode 3: the encoder's choice, see the _sl entry points) */
 } sicn_codec_info;
 
 /* Upper bound of the container size / device scratch needed for n_symbols latent bytes. */
@@ -101,6 +103,26 @@ int sicn_codec_decode_batch_async(const uint8_t *containers, size_t slot_bytes, 
                                   uint32_t n_images, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c, uint8_t *latents,
                                   size_t latent_stride, sicn_codec_status *status_dev, void *workspace, size_t workspace_bytes,
                                   void *hip_stream);
+
+/* The same pair with the STREAM LENGTH as an encoder parameter (mode 3 containers carry it in header dword 9, so every decoder
+ * of this library — and the oracle — reads containers of any admissible length): stream_symbols = a power of two, 1024 ..
+ * 16384 (SICN_CODEC_WSTREAM_SYMBOLS, what the entry points above use).  A stream is a serial chain of stream_symbols / 64
+ * steps on one wave: a 1080p latent (1.57 M symbols) is 96 streams of 16384 — 96 waves on 256 CUs, ≈ 50 / 62 us to encode /
+ * decode — or 383 streams of 4096 at a quarter of that; each extra stream costs 260 bytes (its 64 final states and its length
+ * entry: + 11 % bytes at 4096 on that latent, + 3 % at 8192).  Large batches (8 x 4K: 3040 streams of 16384) gain nothing.
+ * Size the slots and the workspace with the _sl functions; the decoder must be given the same length (a container whose
+ * header disagrees is an error, bit 2). */
+size_t sicn_codec_max_bytes_sl(uint32_t n_symbols, uint32_t stream_symbols);
+size_t sicn_codec_workspace_bytes_sl(uint32_t n_symbols, uint32_t stream_symbols);
+size_t sicn_codec_batch_workspace_bytes_sl(uint32_t n_symbols, uint32_t n_images, uint32_t stream_symbols);
+int sicn_codec_encode_batch_async_sl(const uint8_t *latents, uint32_t n_images, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c,
+                                     uint32_t image_width, uint32_t image_height, uint8_t *out, size_t slot_bytes,
+                                     sicn_codec_status *status_dev, void *workspace, size_t workspace_bytes, void *hip_stream,
+                                     uint32_t stream_symbols);
+int sicn_codec_decode_batch_async_sl(const uint8_t *containers, size_t slot_bytes, const sicn_codec_status *valid_dev_or_null,
+                                     uint32_t n_images, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c, uint8_t *latents,
+                                     size_t latent_stride, sicn_codec_status *status_dev, void *workspace, size_t workspace_bytes,
+                                     void *hip_stream, uint32_t stream_symbols);
 
 /* Mode 4, "rANS-WC": the hyperprior / context-model coder (BASELINE.json configs[4]; no reference
  * counterpart; specification: oracle/sicn_hyper_oracle.c).  Besides the latent both sides hold a SCALE MAP of the same

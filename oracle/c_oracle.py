@@ -59,6 +59,10 @@ def lib() -> ctypes.CDLL:
         L.sicl_or_max_bytes.restype = ctypes.c_size_t
         L.sicl_or_encode.argtypes = [ctypes.c_int, p] + [ctypes.c_uint32] * 5 + [p, ctypes.c_size_t]
         L.sicl_or_encode.restype = ctypes.c_longlong
+        L.sicl_or_max_bytes_sl.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
+        L.sicl_or_max_bytes_sl.restype = ctypes.c_size_t
+        L.sicl_or_encode_sl.argtypes = [ctypes.c_int, p] + [ctypes.c_uint32] * 5 + [p, ctypes.c_size_t, ctypes.c_uint32]
+        L.sicl_or_encode_sl.restype = ctypes.c_longlong
         L.sicl_or_decode.argtypes = [p, ctypes.c_size_t, p, ctypes.c_size_t, p]
         L.sicl_or_decode.restype = ctypes.c_longlong
         L.sicl_or_normalize.argtypes = [p, ctypes.c_uint32, p]
@@ -69,14 +73,20 @@ def lib() -> ctypes.CDLL:
     return _LIB
 
 
-def codec_encode(latent: np.ndarray, image_wh=(0, 0), mode: int = 2) -> bytes:
-    """Oracle statement of the "SICL" container (sicn_codec_oracle.c). latent: [h][w][c] uint8."""
+def codec_encode(latent: np.ndarray, image_wh=(0, 0), mode: int = 2, stream_symbols: int | None = None) -> bytes:
+    """Oracle statement of the "SICL" container (sicn_codec_oracle.c). latent: [h][w][c] uint8.  stream_symbols (mode 3 only):
+    the encoder's stream length, a power of two in 1024 .. 16384 (None = the default, 16384)."""
     latent = np.ascontiguousarray(latent, dtype=np.uint8)
     h, w, c = latent.shape
     L = lib()
-    cap = L.sicl_or_max_bytes(mode, latent.size)
-    out = np.zeros(max(cap, 64), np.uint8)
-    n = L.sicl_or_encode(mode, _ptr(latent), w, h, c, image_wh[0], image_wh[1], _ptr(out), out.size)
+    if stream_symbols is None:
+        cap = L.sicl_or_max_bytes(mode, latent.size)
+        out = np.zeros(max(cap, 64), np.uint8)
+        n = L.sicl_or_encode(mode, _ptr(latent), w, h, c, image_wh[0], image_wh[1], _ptr(out), out.size)
+    else:
+        cap = L.sicl_or_max_bytes_sl(mode, latent.size, stream_symbols)
+        out = np.zeros(max(cap, 64), np.uint8)
+        n = L.sicl_or_encode_sl(mode, _ptr(latent), w, h, c, image_wh[0], image_wh[1], _ptr(out), out.size, stream_symbols)
     if n < 0:
         raise RuntimeError(f"sicl_or_encode rc={n}")
     return out[:n].tobytes()

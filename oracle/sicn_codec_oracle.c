@@ -12,7 +12,8 @@
  *     0  char  magic[4] = "SICL"        4  u16 version = 1        6  u16 mode (0 raw8, 1 packed7, 2 rans, 3 rans-w)
  *     8  u32 image_width  12 u32 image_height   (the RGB image the latent came from)
  *    16  u32 lat_w        20 u32 lat_h          24 u32 lat_c      28 u32 n_symbols = lat_w*lat_h*lat_c
- *    32  u32 n_streams    36 u32 stream_symbols (1024, mode 3: 16384; the last stream may be shorter)
+ *    32  u32 n_streams    36 u32 stream_symbols (1024; mode 3: the encoder's choice of 1024 .. 16384, a power of two,
+ *                            default 16384; the last stream may be shorter)
  *    40  u32 payload_bytes                      44 u32 adler32 of the n_symbols latent bytes
  *   modes 2, 3: u16 freq[128] (sum 4096), then u32 stream_bytes[n_streams]
  *   payload: mode 0: the latent bytes ([lat_h][lat_w][lat_c] order); mode 1: 8 symbols -> 7 bytes
@@ -100,14 +101,22 @@ int sicl_or_normalize(const uint32_t h[128], uint32_t n, uint16_t f[128])
 
 static uint32_t stream_symbols(int mode) { return mode == 3 ? SICL_WSTREAM_SYMBOLS : SICL_STREAM_SYMBOLS; }
 
-size_t sicl_or_max_bytes(int mode, uint32_t n)
+/* Mode 3 with a stream length chosen by the encoder (header dword 9 carries it): a power of two, 1024 .. 16384.  Shorter
+ * streams = more independent waves on the GPU = a shorter critical path for small latents, at 260 bytes per extra stream
+ * (the 64 final states + the length entry).  Everything else about the format is the same. */
+static int wstream_ok(uint32_t ss) { return ss >= 1024u && ss <= SICL_WSTREAM_SYMBOLS && (ss & (ss - 1u)) == 0; }
+
+size_t sicl_or_max_bytes_sl(int mode, uint32_t n, uint32_t ss)
 {
-    const uint32_t ss = stream_symbols(mode), ns = (n + ss - 1) / ss;
+    if (mode == 3 ? !wstream_ok(ss) : ss != stream_symbols(mode)) return 0;   /* not a stream length of this mode */
+    const uint32_t ns = (n + ss - 1) / ss;
     if (mode == 3) return SICL_HEADER + 256 + 4 * (size_t)ns + 2 * (size_t)n + 256 * (size_t)ns;
     if (mode == 0) return SICL_HEADER + (size_t)n;
     if (mode == 1) return SICL_HEADER + ((size_t)n + 7) / 8 * 7;
     return SICL_HEADER + 256 + 4 * (size_t)ns + 2 * (size_t)n + 8 * (size_t)ns;
 }
+
+size_t sicl_or_max_bytes(int mode, uint32_t n) { return sicl_or_max_bytes_sl(mode, n, stream_symbols(mode)); }
 
 /* one stream: returns bytes produced, written at the END of buf[0..cap) */
 static uint32_t rans_encode_stream(const uint8_t *sym, uint32_t n, const uint16_t *freq, const uint16_t *cum,
@@ -167,15 +176,15 @@ static uint32_t ransw_encode_stream(const uint8_t *sym, uint32_t n, const uint16
 }
 
 /* Returns container bytes written, or a negative code (-22 bad argument / symbol >= 128, -28 no space). */
-long long sicl_or_encode(int mode, const uint8_t *latent, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c,
-                         uint32_t img_w, uint32_t img_h, uint8_t *out, size_t cap)
+long long sicl_or_encode_sl(int mode, const uint8_t *latent, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c,
+                            uint32_t img_w, uint32_t img_h, uint8_t *out, size_t cap, uint32_t ss_enc)
 {
     const uint64_t n64 = (uint64_t)lat_w * lat_h * lat_c;
     if (mode < 0 || mode > 3 || n64 > 0x7fffffffu) return -22;
+    if (mode == 3 ? !wstream_ok(ss_enc) : ss_enc != stream_symbols(mode)) return -22;
     const uint32_t n = (uint32_t)n64;
-    const uint32_t ss_enc = stream_symbols(mode);
     const uint32_t ns = (n + ss_enc - 1) / ss_enc;
-    if (cap < sicl_or_max_bytes(mode, n)) return -28;
+    if (cap < sicl_or_max_bytes_sl(mode, n, ss_enc)) return -28;
     uint32_t h[256] = {0};
     for (uint32_t i = 0; i < n; i++) h[latent[i]]++;
     for (int s = 128; s < 256; s++)
@@ -235,6 +244,12 @@ long long sicl_or_encode(int mode, const uint8_t *latent, uint32_t lat_w, uint32
     return (long long)pos;
 }
 
+long long sicl_or_encode(int mode, const uint8_t *latent, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c,
+                         uint32_t img_w, uint32_t img_h, uint8_t *out, size_t cap)
+{
+    return sicl_or_encode_sl(mode, latent, lat_w, lat_h, lat_c, img_w, img_h, out, cap, stream_symbols(mode < 0 || mode > 3 ? 0 : mode));
+}
+
 /* info[8] = mode, img_w, img_h, lat_w, lat_h, lat_c, n_symbols, payload_bytes. Returns symbols
  * decoded or a negative code (-22 malformed, -28 latent_cap too small, -74 checksum mismatch). */
 long long sicl_or_decode(const uint8_t *in, size_t bytes, uint8_t *latent, size_t latent_cap, uint32_t info[8])
@@ -242,7 +257,7 @@ long long sicl_or_decode(const uint8_t *in, size_t bytes, uint8_t *latent, size_
     if (bytes < SICL_HEADER || memcmp(in, "SICL", 4) || get16(in + 4) != 1) return -22;
     const uint32_t mode = get16(in + 6), n = get32(in + 28), ns = get32(in + 32), ss = get32(in + 36);
     const uint32_t payload = get32(in + 40);
-    if (mode > 3 || ss != stream_symbols((int)mode) || ns != (n + ss - 1) / ss) return -22;
+    if (mode > 3 || (mode == 3 ? !wstream_ok(ss) : ss != stream_symbols((int)mode)) || ns != (n + ss - 1) / ss) return -22;
     if ((uint64_t)get32(in + 16) * get32(in + 20) * get32(in + 24) != n) return -22;
     if (info) {
         info[0] = mode; info[1] = get32(in + 8); info[2] = get32(in + 12); info[3] = get32(in + 16);

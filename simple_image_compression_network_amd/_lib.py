@@ -62,7 +62,7 @@ ABI = {
 class CodecInfo(ctypes.Structure):
     """ctypes image of `sicn_codec_info` (include/sicn_codec.h)."""
     _fields_ = [(n, ctypes.c_uint32) for n in ("mode", "image_width", "image_height", "lat_w", "lat_h", "lat_c",
-                                               "n_symbols", "n_streams", "payload_bytes", "adler32")]
+                                               "n_symbols", "n_streams", "payload_bytes", "adler32", "stream_symbols")]
 
 
 class CConvLayerDesc(ctypes.Structure):
@@ -107,6 +107,11 @@ CODEC_ABI = {
     "sicn_codec_decode_batch": (_i, [_vp, _sz, ctypes.POINTER(_sz), _u32, _vp, _sz, ctypes.POINTER(CodecInfo), _vp, _sz, _vp]),
     "sicn_codec_encode_batch_async": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _sz, _vp, _vp, _sz, _vp]),
     "sicn_codec_decode_batch_async": (_i, [_vp, _sz, _vp, _u32, _u32, _u32, _u32, _vp, _sz, _vp, _vp, _sz, _vp]),
+    "sicn_codec_max_bytes_sl": (_sz, [_u32, _u32]),
+    "sicn_codec_workspace_bytes_sl": (_sz, [_u32, _u32]),
+    "sicn_codec_batch_workspace_bytes_sl": (_sz, [_u32, _u32, _u32]),
+    "sicn_codec_encode_batch_async_sl": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _sz, _vp, _vp, _sz, _vp, _u32]),
+    "sicn_codec_decode_batch_async_sl": (_i, [_vp, _sz, _vp, _u32, _u32, _u32, _u32, _vp, _sz, _vp, _vp, _sz, _vp, _u32]),
     "sicn_codec_ctx_max_bytes": (_sz, [_u32, _u32, _u32]),
     "sicn_codec_ctx_workspace_bytes": (_sz, [_u32, _u32, _u32, _u32]),
     "sicn_codec_ctx_encode_batch_async": (_i, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _sz, _vp, _vp, _sz, _vp]),

@@ -10,7 +10,20 @@ from . import _lib
 
 RAW8, PACKED7, RANS, RANSW, RANSWC = 0, 1, 2, 3, 4
 __all__ = ["RAW8", "PACKED7", "RANS", "RANSW", "RANSWC", "encode_latent", "decode_latent", "parse_header", "encode_latents",
-           "decode_latents", "LatentCoder", "ContextCoder"]
+           "decode_latents", "LatentCoder", "ContextCoder", "auto_stream_symbols", "WSTREAM_SYMBOLS"]
+
+
+WSTREAM_SYMBOLS = 16384   # SICN_CODEC_WSTREAM_SYMBOLS: the default (and longest) rANS-W stream
+
+
+def auto_stream_symbols(n_symbols: int, n_images: int = 1) -> int:
+    """The longest admissible stream (best compression) that still gives the chip about two waves per CU: a stream is a serial
+    chain on ONE wave, so a small latent coded in few long streams leaves the GPU idle for the length of that chain.
+    8 x 4K latents: 16384 (3040 streams); one 1080p latent: 4096 (383 streams, + 11 % bytes, a quarter of the latency)."""
+    for ss in (16384, 8192, 4096, 2048):
+        if -(-n_symbols // ss) * n_images >= 512:
+            return ss
+    return 2048 if n_symbols * n_images >= 2048 * 64 else 1024
 
 
 def _stream_ptr(stream):
@@ -50,7 +63,8 @@ def decode_latent(container, stream=None):
     info = parse_header(bytes(container[:48].cpu().numpy().tobytes()))
     n = int(info.n_symbols)
     latent = torch.empty((int(info.lat_h), int(info.lat_w), int(info.lat_c)), dtype=torch.uint8, device=container.device)
-    ws = torch.empty(max(L.sicn_codec_workspace_bytes(int(info.mode), n), 64), dtype=torch.uint8, device=container.device)
+    need = L.sicn_codec_workspace_bytes_sl(n, int(info.stream_symbols)) if int(info.mode) == RANSW else L.sicn_codec_workspace_bytes(int(info.mode), n)
+    ws = torch.empty(max(need, 64), dtype=torch.uint8, device=container.device)
     container = container.contiguous()
     _lib.check(L.sicn_codec_decode(ctypes.c_void_p(container.data_ptr()), container.numel(),
                                    ctypes.c_void_p(latent.data_ptr()), max(n, 1), ctypes.byref(info),
@@ -86,7 +100,7 @@ def decode_latents(slots, sizes, stream=None):
     info0 = parse_header(bytes(slots[0, :48].cpu().numpy().tobytes()))
     n = int(info0.n_symbols)
     latents = torch.empty((nimg, int(info0.lat_h), int(info0.lat_w), int(info0.lat_c)), dtype=torch.uint8, device=slots.device)
-    ws = torch.empty(max(L.sicn_codec_batch_workspace_bytes(RANSW, n, nimg), 64), dtype=torch.uint8, device=slots.device)
+    ws = torch.empty(max(L.sicn_codec_batch_workspace_bytes_sl(n, nimg, int(info0.stream_symbols)), 64), dtype=torch.uint8, device=slots.device)
     csz = (ctypes.c_size_t * nimg)(*sizes)
     infos = (_lib.CodecInfo * nimg)()
     slots = slots.contiguous()
@@ -103,16 +117,23 @@ class LatentCoder:
     one hipGraph).  Verdicts and sizes stay on the device until `check()` / `sizes()` fetch them."""
 
     def __init__(self, n_images: int, lat_h: int, lat_w: int, lat_c: int, image_width: int = 0, image_height: int = 0,
-                 device="cuda"):
+                 device="cuda", stream_symbols=None):
+        """stream_symbols: None = 16384 (the format's default), "auto" = `auto_stream_symbols`, or a power of two 1024 .. 16384
+        (sicn_codec_*_async_sl: shorter streams = shorter critical path on small latents, 260 bytes per extra stream).  A
+        decoder object must be built with the encoder's value."""
         import torch
         L = _lib.lib()
         self.shape = (int(n_images), int(lat_h), int(lat_w), int(lat_c))
         self.image_wh = (int(image_width), int(image_height))
         n = lat_h * lat_w * lat_c
-        self.slot = (int(L.sicn_codec_max_bytes(RANSW, n)) + 255) // 256 * 256
+        self.stream_symbols = (WSTREAM_SYMBOLS if stream_symbols is None else
+                               auto_stream_symbols(n, n_images) if stream_symbols == "auto" else int(stream_symbols))
+        if self.stream_symbols not in (1024, 2048, 4096, 8192, 16384):
+            raise ValueError("stream_symbols must be a power of two in 1024 .. 16384")
+        self.slot = (int(L.sicn_codec_max_bytes_sl(n, self.stream_symbols)) + 255) // 256 * 256
         dev = torch.device(device)
         self.slots = torch.empty((n_images, self.slot), dtype=torch.uint8, device=dev)
-        self.ws = torch.empty(max(L.sicn_codec_batch_workspace_bytes(RANSW, n, n_images), 256), dtype=torch.uint8, device=dev)
+        self.ws = torch.empty(max(L.sicn_codec_batch_workspace_bytes_sl(n, n_images, self.stream_symbols), 256), dtype=torch.uint8, device=dev)
         self.enc_status = torch.zeros((n_images, 2), dtype=torch.int32, device=dev)   # sicn_codec_status {error, bytes}
         self.dec_status = torch.zeros((n_images, 2), dtype=torch.int32, device=dev)
 
@@ -122,10 +143,10 @@ class LatentCoder:
         if not (latents.is_cuda and latents.dtype == torch.uint8 and latents.is_contiguous() and tuple(latents.shape) == self.shape):
             raise TypeError(f"latents must be a contiguous CUDA uint8 tensor of shape {self.shape}")
         n, h, w, c = self.shape
-        _lib.check(_lib.lib().sicn_codec_encode_batch_async(
+        _lib.check(_lib.lib().sicn_codec_encode_batch_async_sl(
             ctypes.c_void_p(latents.data_ptr()), n, w, h, c, self.image_wh[0], self.image_wh[1],
             ctypes.c_void_p(self.slots.data_ptr()), self.slot, ctypes.c_void_p(self.enc_status.data_ptr()),
-            ctypes.c_void_p(self.ws.data_ptr()), self.ws.numel(), _stream_ptr(stream)), "sicn_codec_encode_batch_async")
+            ctypes.c_void_p(self.ws.data_ptr()), self.ws.numel(), _stream_ptr(stream), self.stream_symbols), "sicn_codec_encode_batch_async_sl")
         return self.slots
 
     def decode(self, out_latents, slots=None, valid=None, stream=None):
@@ -142,10 +163,10 @@ class LatentCoder:
             raise TypeError("slots must be a contiguous CUDA uint8 tensor [n][slot_bytes]")
         own = slots is self.slots
         vptr = None if (valid is False or (valid is None and not own)) else ctypes.c_void_p((self.enc_status if valid is None else valid).data_ptr())
-        _lib.check(_lib.lib().sicn_codec_decode_batch_async(
+        _lib.check(_lib.lib().sicn_codec_decode_batch_async_sl(
             ctypes.c_void_p(slots.data_ptr()), self.slot, vptr, n, w, h, c, ctypes.c_void_p(out_latents.data_ptr()), h * w * c,
-            ctypes.c_void_p(self.dec_status.data_ptr()), ctypes.c_void_p(self.ws.data_ptr()), self.ws.numel(), _stream_ptr(stream)),
-            "sicn_codec_decode_batch_async")
+            ctypes.c_void_p(self.dec_status.data_ptr()), ctypes.c_void_p(self.ws.data_ptr()), self.ws.numel(), _stream_ptr(stream),
+            self.stream_symbols), "sicn_codec_decode_batch_async_sl")
         return out_latents
 
     def sizes(self):

@@ -31,6 +31,10 @@ constexpr uint32_t WCAP = 2 * WSS + 256;               // at most one 16-bit wor
 constexpr uint32_t RANSW_L = 1u << 16;
 inline uint32_t stream_symbols(int mode) { return mode == SICN_CODEC_RANSW ? WSS : SS; }
 inline uint32_t stream_cap(int mode) { return mode == SICN_CODEC_RANSW ? WCAP : CAP; }
+// mode 3 with the encoder's choice of stream length (header dword 9): a power of two, 1024 .. 16384 symbols.  Shorter streams =
+// more waves = a shorter serial chain for a small latent, + 260 bytes per stream (64 final states, one length entry).
+__host__ __device__ inline bool wstream_ok(uint32_t wss) { return wss >= 1024u && wss <= WSS && (wss & (wss - 1u)) == 0; }
+__host__ __device__ inline uint32_t wstream_cap(uint32_t wss) { return 2u * wss + 256u; }   // scratch bytes per stream (= WCAP at 16384)
 constexpr uint32_t RANS_L = 1u << 23;
 constexpr int PROB_BITS = 12;
 constexpr uint32_t ADLER_MOD = 65521u;
@@ -218,7 +222,7 @@ __device__ __forceinline__ uint32_t ring_fill(uint16_t *ring, const uint16_t *sr
 
 __global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__ lat_, uint32_t n, uint32_t ns,
                                                      const uint16_t *__restrict__ freq_g_, uint8_t *__restrict__ scratch_,
-                                                     uint32_t *__restrict__ lens_, size_t s_lat, size_t s_ws)
+                                                     uint32_t *__restrict__ lens_, size_t s_lat, size_t s_ws, uint32_t wss)
 {
     const uint8_t *lat = img_ptr(lat_, s_lat);
     const uint16_t *freq_g = img_ptr(freq_g_, s_ws);
@@ -229,10 +233,11 @@ __global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__
     const uint32_t st = blockIdx.x, lane = threadIdx.x;
     ransw_build(tab, freq_g, (int)lane);
     __syncthreads();
-    const uint32_t begin = st * WSS, cnt = min(WSS, n - begin), blocks = (cnt + 255) / 256;
-    const bool aligned = (reinterpret_cast<uintptr_t>(lat) & 3) == 0;   // begin is a multiple of 16384
-    uint16_t *dst = (uint16_t *)(scratch + (size_t)st * WCAP);
-    uint32_t pos = WCAP / 2, top = WCAP / 2;   // word indices inside the scratch slot, the same in every lane: [pos, top) is in the ring
+    const uint32_t wcap = wstream_cap(wss);
+    const uint32_t begin = st * wss, cnt = min(wss, n - begin), blocks = (cnt + 255) / 256;
+    const bool aligned = (reinterpret_cast<uintptr_t>(lat) & 3) == 0;   // begin is a multiple of the stream length (>= 1024)
+    uint16_t *dst = (uint16_t *)(scratch + (size_t)st * wcap);
+    uint32_t pos = wcap / 2, top = wcap / 2;   // word indices inside the scratch slot, the same in every lane: [pos, top) is in the ring
     uint32_t x = RANSW_L;
     const unsigned long long below = (1ull << lane) - 1;
     auto load4 = [&](uint32_t q) -> uint32_t {   // the lane's 4 symbols of block q (missing ones read as 0)
@@ -281,14 +286,14 @@ __global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__
     words[(pos + 2 * lane + 1) & (RING_WORDS - 1)] = (uint16_t)(x >> 16);
     __syncthreads();
     ring_flush(words, dst, pos, top, lane);
-    if (lane == 0) lens[st] = (WCAP / 2 - pos) * 2;
+    if (lane == 0) lens[st] = (wcap / 2 - pos) * 2;
 }
 
 __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__ payload_, const uint8_t *__restrict__ freq_bytes_,
                                                      const uint32_t *__restrict__ offsets_, uint32_t n, uint32_t ns,
                                                      uint8_t *__restrict__ lat_, uint32_t *__restrict__ err_, size_t s_slot,
                                                      size_t s_ws, size_t s_lat, const uint8_t *__restrict__ payload_bytes_field_,
-                                                     const uint32_t *__restrict__ meta_, unsigned long long *__restrict__ sums_ = nullptr)
+                                                     const uint32_t *__restrict__ meta_, unsigned long long *__restrict__ sums_, uint32_t wss)
 {
     const uint8_t *payload = img_ptr(payload_, s_slot), *freq_bytes = img_ptr(freq_bytes_, s_slot);
     // header field "payload bytes" of this image's container (the host has checked it against the bytes it was
@@ -313,9 +318,9 @@ __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__
         const uint32_t t = tab.fc[2 * lane + k], f = t & 0xFFFFu, c = t >> 16;
         for (uint32_t v = c; v < c + f && v < 4096; v++) slot[v] = (uint8_t)(2 * lane + k);
     }
-    const uint32_t begin = st * WSS, cnt = min(WSS, n - begin), blocks = (cnt + 255) / 256;
+    const uint32_t begin = st * wss, cnt = min(wss, n - begin), blocks = (cnt + 255) / 256;
     const uint32_t off = offsets[st], len = offsets[st + 1] - off;
-    if (len < 256 || (len & 1) || (off & 1) || len > WCAP ||
+    if (len < 256 || (len & 1) || (off & 1) || len > wstream_cap(wss) ||
         (unsigned long long)off + len > payload_bytes) {   // streams start at even container offsets
         if (lane == 0) atomicOr(err, 1u);
         return;
@@ -582,7 +587,7 @@ __device__ __forceinline__ void clear_stats_in_parse(uint32_t *meta, int lane)
 __global__ __launch_bounds__(64) void k_enc_header(const uint32_t *__restrict__ hist_, const unsigned long long *__restrict__ sums_,
                                                    uint16_t *__restrict__ freq_, uint8_t *__restrict__ out_, uint32_t *__restrict__ status_,
                                                    uint32_t n, uint32_t ns, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c,
-                                                   uint32_t img_w, uint32_t img_h, size_t s_ws, size_t s_slot)
+                                                   uint32_t img_w, uint32_t img_h, size_t s_ws, size_t s_slot, uint32_t wss)
 {
     const uint32_t *hist = img_ptr(hist_, s_ws);
     const unsigned long long *sums = img_ptr(sums_, s_ws);
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(64) void k_enc_header(const uint32_t *__restrict__ 
         const unsigned long long s1 = sums[0], s2 = sums[1];
         const uint32_t a = (uint32_t)((1 + s1) % ADLER_MOD), b = (uint32_t)((n % ADLER_MOD + s2) % ADLER_MOD);
         const uint32_t words[12] = {0x4C434953u /* "SICL" */, 1u | ((uint32_t)SICN_CODEC_RANSW << 16), img_w, img_h, lat_w, lat_h,
-                                    lat_c, n, ns, WSS, 0u, (b << 16) | a};
+                                    lat_c, n, ns, wss, 0u, (b << 16) | a};
         if (lane != 10) {
             const uint32_t v = words[lane];
             uint8_t *p = out + 4 * lane;
@@ -644,7 +649,7 @@ __global__ __launch_bounds__(64) void k_enc_header(const uint32_t *__restrict__ 
 // against the bytes the caller vouches for.  meta[0] |= error bits, meta[1] = payload bytes the streams may use.
 __global__ __launch_bounds__(64) void k_dec_parse(const uint8_t *__restrict__ containers_, const uint32_t *__restrict__ valid_bytes_,
                                                   uint32_t valid_stride, uint32_t *__restrict__ meta_, uint32_t n, uint32_t ns,
-                                                  uint32_t lat_w, uint32_t lat_h, uint32_t lat_c, size_t s_slot, size_t s_ws)
+                                                  uint32_t lat_w, uint32_t lat_h, uint32_t lat_c, size_t s_slot, size_t s_ws, uint32_t wss)
 {
     const uint8_t *c = img_ptr(containers_, s_slot);
     uint32_t *meta = img_ptr(meta_, s_ws);
@@ -659,7 +664,7 @@ __global__ __launch_bounds__(64) void k_dec_parse(const uint8_t *__restrict__ co
         return;
     }
     auto rd32 = [&](int o) { return c[o] | ((uint32_t)c[o + 1] << 8) | ((uint32_t)c[o + 2] << 16) | ((uint32_t)c[o + 3] << 24); };
-    const uint32_t expect[10] = {0x4C434953u, 1u | ((uint32_t)SICN_CODEC_RANSW << 16), 0, 0, lat_w, lat_h, lat_c, n, ns, WSS};
+    const uint32_t expect[10] = {0x4C434953u, 1u | ((uint32_t)SICN_CODEC_RANSW << 16), 0, 0, lat_w, lat_h, lat_c, n, ns, wss};
     if (lane < 10 && lane != 2 && lane != 3 && rd32(4 * lane) != expect[lane]) err = 4;
     uint32_t fsum = c[SICN_CODEC_HEADER_BYTES + 4 * lane] + ((uint32_t)c[SICN_CODEC_HEADER_BYTES + 4 * lane + 1] << 8) +
                     c[SICN_CODEC_HEADER_BYTES + 4 * lane + 2] + ((uint32_t)c[SICN_CODEC_HEADER_BYTES + 4 * lane + 3] << 8);
@@ -769,6 +774,33 @@ extern "C" long long sicn_codec_selftest_div(uint32_t f_begin, uint32_t f_end, u
     return bad;
 }
 
+// 32-bit stream offsets: ceil(n / wss) scratch slots of wstream_cap(wss) bytes must stay below 2^32 (the static_assert above is
+// the 16384 case; 1024-symbol streams allow 1.9 G symbols)
+static bool wstream_fits(unsigned long long n, uint32_t wss)
+{
+    return n <= MAX_RANS_SYMBOLS && ((n + wss - 1) / wss) * (unsigned long long)wstream_cap(wss) < (1ull << 32);
+}
+
+extern "C" size_t sicn_codec_max_bytes_sl(uint32_t n, uint32_t wss)
+{
+    if (!wstream_ok(wss)) return 0;
+    const uint32_t ns = (n + wss - 1) / wss;
+    return SICN_CODEC_HEADER_BYTES + 256 + 4 * (size_t)ns + 2 * (size_t)n + 256 * (size_t)ns;
+}
+
+extern "C" size_t sicn_codec_workspace_bytes_sl(uint32_t n, uint32_t wss)
+{
+    if (!wstream_ok(wss)) return 0;
+    Workspace w;
+    return carve(w, nullptr, (n + wss - 1) / wss, wstream_cap(wss)) + 64;
+}
+
+extern "C" size_t sicn_codec_batch_workspace_bytes_sl(uint32_t n_symbols, uint32_t n_images, uint32_t wss)
+{
+    if (!wstream_ok(wss)) return 0;
+    return (size_t)n_images * align_up(sicn_codec_workspace_bytes_sl(n_symbols, wss), 256) + align_up(16 * (size_t)n_images, 256);
+}
+
 extern "C" size_t sicn_codec_max_bytes(int mode, uint32_t n)
 {
     const uint32_t ns = (n + stream_symbols(mode) - 1) / stream_symbols(mode);
@@ -800,9 +832,13 @@ extern "C" int sicn_codec_parse_header(const uint8_t *h, size_t bytes, sicn_code
     info->n_streams = get32(h + 32);
     info->payload_bytes = get32(h + 40);
     info->adler32 = get32(h + 44);
-    if (info->mode > 4 || get32(h + 36) != stream_symbols(info->mode == 4 ? 3 : (int)info->mode)) return SICN_EINVAL;
+    info->stream_symbols = get32(h + 36);
+    if (info->mode > 4) return SICN_EINVAL;
+    if (info->mode == SICN_CODEC_RANSW ? !wstream_ok(info->stream_symbols)
+                                       : info->stream_symbols != stream_symbols(info->mode == 4 ? 3 : (int)info->mode))
+        return SICN_EINVAL;
     if ((unsigned long long)info->lat_w * info->lat_h * info->lat_c != info->n_symbols) return SICN_EINVAL;
-    const uint32_t ss = stream_symbols((int)info->mode);
+    const uint32_t ss = info->stream_symbols;
     if (info->mode == 4) {   // anchors and non-anchors are cut into streams separately (sicn_codec_ctx.inc)
         const uint32_t W = info->lat_w, H = info->lat_h, C = info->lat_c;
         const unsigned long long na = ((unsigned long long)(H / 2) * W + ((H & 1) ? (W + 1) / 2 : 0)) * C;
@@ -880,7 +916,7 @@ extern "C" int sicn_codec_encode(int mode, const uint8_t *latent, uint32_t lat_w
         uint8_t *table = out + SICN_CODEC_HEADER_BYTES + 256;
         uint8_t *payload = table + 4 * (size_t)ns;
         if (ns && mode == SICN_CODEC_RANSW)
-            hipLaunchKernelGGL(k_ransw_encode, dim3(ns), dim3(64), 0, stream, latent, n, ns, w.freq, w.scratch, w.lens, (size_t)0, (size_t)0);
+            hipLaunchKernelGGL(k_ransw_encode, dim3(ns), dim3(64), 0, stream, latent, n, ns, w.freq, w.scratch, w.lens, (size_t)0, (size_t)0, WSS);
         else if (ns)
             hipLaunchKernelGGL(k_rans_encode, dim3((ns + 255) / 256), dim3(256), 0, stream, latent, n, ns, w.freq, w.scratch, w.lens);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, w.lens, (const uint8_t *)nullptr, ns, w.offsets, table, out + 40, (size_t)0, (size_t)0,
@@ -912,7 +948,12 @@ extern "C" int sicn_codec_decode(const uint8_t *container, size_t bytes, uint8_t
     const uint32_t n = info.n_symbols, ns = info.n_streams;
     if (n > 0x7fffffffu || (info.mode >= SICN_CODEC_RANS && n > MAX_RANS_SYMBOLS)) return SICN_EINVAL;
     if (n && (!latent || latent_capacity < n)) return SICN_ENOSPC;
-    if (!workspace || workspace_bytes < sicn_codec_workspace_bytes((int)info.mode, n)) return SICN_ENOSPC;
+    const bool wmode = info.mode == SICN_CODEC_RANSW;
+    if (wmode && !wstream_fits(n, info.stream_symbols)) return SICN_EINVAL;
+    // (a caller that sized the workspace for the default stream length needs sicn_codec_workspace_bytes_sl for shorter streams)
+    if (!workspace || workspace_bytes < (wmode ? sicn_codec_workspace_bytes_sl(n, info.stream_symbols)
+                                               : sicn_codec_workspace_bytes((int)info.mode, n)))
+        return SICN_ENOSPC;
     Workspace w;
     carve(w, workspace, ns, 0);
     HIP_TRY(hipMemsetAsync(w.hist, 0, 1024 + 64, stream));
@@ -940,14 +981,15 @@ extern "C" int sicn_codec_decode(const uint8_t *container, size_t bytes, uint8_t
             if (sum != 4096) return SICN_EINVAL;
         }
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, (const uint32_t *)nullptr, table, ns, w.offsets,
-                           (uint8_t *)nullptr, (uint8_t *)nullptr, (size_t)0, (size_t)0, stream_cap((int)info.mode), err);
+                           (uint8_t *)nullptr, (uint8_t *)nullptr, (size_t)0, (size_t)0,
+                           wmode ? wstream_cap(info.stream_symbols) : stream_cap((int)info.mode), err);
         uint32_t total = 0;
         HIP_TRY(hipMemcpyAsync(&total, w.offsets + ns, 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (total != info.payload_bytes) return SICN_EINVAL;
         if (ns && info.mode == SICN_CODEC_RANSW)
             hipLaunchKernelGGL(k_ransw_decode, dim3(ns), dim3(64), 0, stream, payload, freq_bytes, w.offsets, n, ns, latent, err, (size_t)0, (size_t)0, (size_t)0,
-                               container + 40, (const uint32_t *)nullptr);
+                               container + 40, (const uint32_t *)nullptr, (unsigned long long *)nullptr, info.stream_symbols);
         else if (ns)
             hipLaunchKernelGGL(k_rans_decode, dim3((ns + 255) / 256), dim3(256), 0, stream, payload, freq_bytes, w.offsets, n, ns, latent, err,
                                info.payload_bytes);
@@ -978,22 +1020,22 @@ extern "C" size_t sicn_codec_batch_workspace_bytes(int mode, uint32_t n_symbols,
     return (size_t)n_images * align_up(sicn_codec_workspace_bytes(mode, n_symbols), 256) + align_up(16 * (size_t)n_images, 256);
 }
 
-extern "C" int sicn_codec_encode_batch_async(const uint8_t *latents, uint32_t n_images, uint32_t lat_w, uint32_t lat_h,
-                                             uint32_t lat_c, uint32_t img_w, uint32_t img_h, uint8_t *out, size_t slot_bytes,
-                                             sicn_codec_status *status_dev, void *workspace, size_t workspace_bytes,
-                                             void *hip_stream)
+extern "C" int sicn_codec_encode_batch_async_sl(const uint8_t *latents, uint32_t n_images, uint32_t lat_w, uint32_t lat_h,
+                                                uint32_t lat_c, uint32_t img_w, uint32_t img_h, uint8_t *out, size_t slot_bytes,
+                                                sicn_codec_status *status_dev, void *workspace, size_t workspace_bytes,
+                                                void *hip_stream, uint32_t wss)
 {
-    if (!out || !status_dev) return SICN_EINVAL;
+    if (!out || !status_dev || !wstream_ok(wss)) return SICN_EINVAL;
     const unsigned long long n64 = (unsigned long long)lat_w * lat_h * lat_c;
-    if (n64 > MAX_RANS_SYMBOLS || (n64 && !latents) || n_images > 65535) return SICN_EINVAL;
+    if (!wstream_fits(n64, wss) || (n64 && !latents) || n_images > 65535) return SICN_EINVAL;
     if (n_images == 0) return SICN_OK;
-    const uint32_t n = (uint32_t)n64, ns = (n + WSS - 1) / WSS;
-    if (slot_bytes < sicn_codec_max_bytes(SICN_CODEC_RANSW, n) || (slot_bytes & 1)) return SICN_ENOSPC;
-    const size_t ws1 = align_up(sicn_codec_workspace_bytes(SICN_CODEC_RANSW, n), 256);
+    const uint32_t n = (uint32_t)n64, ns = (n + wss - 1) / wss, wcap = wstream_cap(wss);
+    if (slot_bytes < sicn_codec_max_bytes_sl(n, wss) || (slot_bytes & 1)) return SICN_ENOSPC;
+    const size_t ws1 = align_up(sicn_codec_workspace_bytes_sl(n, wss), 256);
     if (!workspace || workspace_bytes < ws1 * n_images) return SICN_ENOSPC;
     hipStream_t stream = (hipStream_t)hip_stream;
     Workspace w;
-    carve(w, workspace, ns, WCAP);
+    carve(w, workspace, ns, wcap);
     uint32_t *status = (uint32_t *)status_dev;
     uint8_t *table = out + SICN_CODEC_HEADER_BYTES + 256, *payload = table + 4 * (size_t)ns;
     const uint32_t fixed = (uint32_t)(SICN_CODEC_HEADER_BYTES + 256 + 4 * (size_t)ns);
@@ -1002,15 +1044,57 @@ extern "C" int sicn_codec_encode_batch_async(const uint8_t *latents, uint32_t n_
         hipLaunchKernelGGL(k_stats, dim3(stats_blocks(n, n_images), n_images), dim3(256), 0, stream, latents, n, w.hist,
                            w.sums, (size_t)n, ws1);
     hipLaunchKernelGGL(k_enc_header, dim3(1, n_images), dim3(64), 0, stream, w.hist, w.sums, w.freq, out, status, n, ns, lat_w,
-                       lat_h, lat_c, img_w, img_h, ws1, slot_bytes);
+                       lat_h, lat_c, img_w, img_h, ws1, slot_bytes, wss);
     if (ns)
         hipLaunchKernelGGL(k_ransw_encode, dim3(ns, n_images), dim3(64), 0, stream, latents, n, ns, w.freq, w.scratch, w.lens,
-                           (size_t)n, ws1);
+                           (size_t)n, ws1, wss);
     hipLaunchKernelGGL(k_scan, dim3(1, n_images), dim3(1024), 0, stream, w.lens, (const uint8_t *)nullptr, ns, w.offsets, table,
                        out + 40, ws1, slot_bytes, 0xFFFFFFFFu, (uint32_t *)nullptr, status, fixed);
     if (ns)
-        hipLaunchKernelGGL(k_compact, dim3(ns, n_images), dim3(256), 0, stream, w.scratch, w.lens, w.offsets, payload, WCAP, ws1,
+        hipLaunchKernelGGL(k_compact, dim3(ns, n_images), dim3(256), 0, stream, w.scratch, w.lens, w.offsets, payload, wcap, ws1,
                            slot_bytes);
+    return hipGetLastError() == hipSuccess ? SICN_OK : SICN_ENODEV;
+}
+
+extern "C" int sicn_codec_encode_batch_async(const uint8_t *latents, uint32_t n_images, uint32_t lat_w, uint32_t lat_h,
+                                             uint32_t lat_c, uint32_t img_w, uint32_t img_h, uint8_t *out, size_t slot_bytes,
+                                             sicn_codec_status *status_dev, void *workspace, size_t workspace_bytes,
+                                             void *hip_stream)
+{
+    return sicn_codec_encode_batch_async_sl(latents, n_images, lat_w, lat_h, lat_c, img_w, img_h, out, slot_bytes, status_dev, workspace,
+                                            workspace_bytes, hip_stream, WSS);
+}
+
+extern "C" int sicn_codec_decode_batch_async_sl(const uint8_t *containers, size_t slot_bytes, const sicn_codec_status *valid_dev_or_null,
+                                                uint32_t n_images, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c, uint8_t *latents,
+                                                size_t latent_stride, sicn_codec_status *status_dev, void *workspace,
+                                                size_t workspace_bytes, void *hip_stream, uint32_t wss)
+{
+    if (!containers || !status_dev || (slot_bytes & 1) || !wstream_ok(wss)) return SICN_EINVAL;
+    const unsigned long long n64 = (unsigned long long)lat_w * lat_h * lat_c;
+    if (!wstream_fits(n64, wss) || n_images > 65535) return SICN_EINVAL;
+    if (n_images == 0) return SICN_OK;
+    const uint32_t n = (uint32_t)n64, ns = (n + wss - 1) / wss;
+    if (n && (!latents || latent_stride < n)) return SICN_ENOSPC;
+    const size_t ws1 = align_up(sicn_codec_workspace_bytes_sl(n, wss), 256);
+    if (!workspace || workspace_bytes < ws1 * n_images) return SICN_ENOSPC;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    Workspace w;
+    carve(w, workspace, ns, 0);
+    const uint8_t *freq_bytes = containers + SICN_CODEC_HEADER_BYTES, *table = freq_bytes + 256, *payload = table + 4 * (size_t)ns;
+    hipLaunchKernelGGL(k_dec_parse, dim3(1, n_images), dim3(64), 0, stream, containers,
+                       valid_dev_or_null ? &valid_dev_or_null->bytes : (const uint32_t *)nullptr, 2u, w.meta, n, ns, lat_w, lat_h,
+                       lat_c, slot_bytes, ws1, wss);
+    // a slot the parse stage rejected as too short is never read: its table counts as empty (ns_eff = 0 via meta[1] = 0 and
+    // the per-stream bound off + len <= payload bytes, so every stream of it flags an error and returns)
+    hipLaunchKernelGGL(k_scan, dim3(1, n_images), dim3(1024), 0, stream, (const uint32_t *)nullptr, table, ns, w.offsets,
+                       (uint8_t *)nullptr, (uint8_t *)nullptr, ws1, slot_bytes, wstream_cap(wss), w.meta + 3, (uint32_t *)nullptr, 0u,
+                       (const uint32_t *)w.meta);
+    if (ns)
+        hipLaunchKernelGGL(k_ransw_decode, dim3(ns, n_images), dim3(64), 0, stream, payload, freq_bytes, w.offsets, n, ns, latents,
+                           w.meta + 3, slot_bytes, ws1, latent_stride, containers + 40, w.meta, w.sums, wss);
+    hipLaunchKernelGGL(k_dec_finish, dim3(1, n_images), dim3(64), 0, stream, w.meta, w.hist, w.sums, w.offsets, (uint32_t *)status_dev,
+                       n, ns, ws1);
     return hipGetLastError() == hipSuccess ? SICN_OK : SICN_ENODEV;
 }
 
@@ -1019,32 +1103,8 @@ extern "C" int sicn_codec_decode_batch_async(const uint8_t *containers, size_t s
                                              size_t latent_stride, sicn_codec_status *status_dev, void *workspace,
                                              size_t workspace_bytes, void *hip_stream)
 {
-    if (!containers || !status_dev || (slot_bytes & 1)) return SICN_EINVAL;
-    const unsigned long long n64 = (unsigned long long)lat_w * lat_h * lat_c;
-    if (n64 > MAX_RANS_SYMBOLS || n_images > 65535) return SICN_EINVAL;
-    if (n_images == 0) return SICN_OK;
-    const uint32_t n = (uint32_t)n64, ns = (n + WSS - 1) / WSS;
-    if (n && (!latents || latent_stride < n)) return SICN_ENOSPC;
-    const size_t ws1 = align_up(sicn_codec_workspace_bytes(SICN_CODEC_RANSW, n), 256);
-    if (!workspace || workspace_bytes < ws1 * n_images) return SICN_ENOSPC;
-    hipStream_t stream = (hipStream_t)hip_stream;
-    Workspace w;
-    carve(w, workspace, ns, 0);
-    const uint8_t *freq_bytes = containers + SICN_CODEC_HEADER_BYTES, *table = freq_bytes + 256, *payload = table + 4 * (size_t)ns;
-    hipLaunchKernelGGL(k_dec_parse, dim3(1, n_images), dim3(64), 0, stream, containers,
-                       valid_dev_or_null ? &valid_dev_or_null->bytes : (const uint32_t *)nullptr, 2u, w.meta, n, ns, lat_w, lat_h,
-                       lat_c, slot_bytes, ws1);
-    // a slot the parse stage rejected as too short is never read: its table counts as empty (ns_eff = 0 via meta[1] = 0 and
-    // the per-stream bound off + len <= payload bytes, so every stream of it flags an error and returns)
-    hipLaunchKernelGGL(k_scan, dim3(1, n_images), dim3(1024), 0, stream, (const uint32_t *)nullptr, table, ns, w.offsets,
-                       (uint8_t *)nullptr, (uint8_t *)nullptr, ws1, slot_bytes, WCAP, w.meta + 3, (uint32_t *)nullptr, 0u,
-                       (const uint32_t *)w.meta);
-    if (ns)
-        hipLaunchKernelGGL(k_ransw_decode, dim3(ns, n_images), dim3(64), 0, stream, payload, freq_bytes, w.offsets, n, ns, latents,
-                           w.meta + 3, slot_bytes, ws1, latent_stride, containers + 40, w.meta, w.sums);
-    hipLaunchKernelGGL(k_dec_finish, dim3(1, n_images), dim3(64), 0, stream, w.meta, w.hist, w.sums, w.offsets, (uint32_t *)status_dev,
-                       n, ns, ws1);
-    return hipGetLastError() == hipSuccess ? SICN_OK : SICN_ENODEV;
+    return sicn_codec_decode_batch_async_sl(containers, slot_bytes, valid_dev_or_null, n_images, lat_w, lat_h, lat_c, latents,
+                                            latent_stride, status_dev, workspace, workspace_bytes, hip_stream, WSS);
 }
 
 static int status_to_rc(uint32_t err)
@@ -1108,19 +1168,21 @@ extern "C" int sicn_codec_decode_batch(const uint8_t *containers, size_t slot_by
         if (rc) return rc;
         if (info[i].mode != SICN_CODEC_RANSW) return SICN_EINVAL;
         if (info[i].lat_w != info[0].lat_w || info[i].lat_h != info[0].lat_h || info[i].lat_c != info[0].lat_c) return SICN_EINVAL;
+        if (info[i].stream_symbols != info[0].stream_symbols) return SICN_EINVAL;   // one batch = one stream length
         if (info[i].n_symbols > MAX_RANS_SYMBOLS) return SICN_EINVAL;
         if (infos_or_null) infos_or_null[i] = info[i];
         st[i].error = 0;
         st[i].bytes = (uint32_t)bytes_host[i];
     }
-    const size_t blocks = (size_t)n_images * align_up(sicn_codec_workspace_bytes(SICN_CODEC_RANSW, info[0].n_symbols), 256);
-    if (!workspace || workspace_bytes < sicn_codec_batch_workspace_bytes(SICN_CODEC_RANSW, info[0].n_symbols, n_images)) return SICN_ENOSPC;
+    const uint32_t wss = info[0].stream_symbols;
+    const size_t blocks = (size_t)n_images * align_up(sicn_codec_workspace_bytes_sl(info[0].n_symbols, wss), 256);
+    if (!workspace || workspace_bytes < sicn_codec_batch_workspace_bytes_sl(info[0].n_symbols, n_images, wss)) return SICN_ENOSPC;
     sicn_codec_status *st_dev = (sicn_codec_status *)((uint8_t *)workspace + blocks);   // [0, n): valid bytes in, [n, 2n): verdicts out
     int rc = hipMemcpyAsync(st_dev, st.data(), sizeof(sicn_codec_status) * n_images, hipMemcpyHostToDevice, stream) == hipSuccess
                  ? SICN_OK : SICN_ENODEV;
     if (rc == SICN_OK)
-        rc = sicn_codec_decode_batch_async(containers, slot_bytes, st_dev, n_images, info[0].lat_w, info[0].lat_h, info[0].lat_c, latents,
-                                           latent_stride, st_dev + n_images, workspace, workspace_bytes, hip_stream);
+        rc = sicn_codec_decode_batch_async_sl(containers, slot_bytes, st_dev, n_images, info[0].lat_w, info[0].lat_h, info[0].lat_c,
+                                              latents, latent_stride, st_dev + n_images, workspace, workspace_bytes, hip_stream, wss);
     if (rc == SICN_OK && hipMemcpyAsync(st.data() + n_images, st_dev + n_images, sizeof(sicn_codec_status) * n_images,
                                         hipMemcpyDeviceToHost, stream) != hipSuccess)
         rc = SICN_ENODEV;

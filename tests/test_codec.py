@@ -82,6 +82,37 @@ def test_wave_form_layout():
     assert b < a * 1.02
 
 
+@pytest.mark.parametrize("ss", [1024, 2048, 4096, 8192, 16384])
+def test_stream_length_is_an_encoder_parameter(ss):
+    """Mode 3 with the encoder's choice of stream length (header dword 9): round trip, stream count, the default entry point
+    = 16384, inadmissible lengths rejected; shorter streams cost 260 bytes each (64 final states + the length entry)."""
+    shape = (9, 10, 192)                                   # 17280 symbols: ragged last stream at every length
+    lat = _mock_latent(np.random.default_rng(21), shape)
+    blob = c_oracle.codec_encode(lat, (160, 144), 3, stream_symbols=ss)
+    magic, ver, mode, iw, ih, lw, lh, lc, n, ns, hss, payload, adler = struct.unpack("<4sHHIIIIIIIIII", blob[:48])
+    assert (mode, n, ns, hss) == (3, 17280, -(-17280 // ss), ss)
+    out, _ = c_oracle.codec_decode(blob)
+    assert np.array_equal(out, lat)
+    assert len(blob) <= c_oracle.lib().sicl_or_max_bytes_sl(3, lat.size, ss)
+    ref = c_oracle.codec_encode(lat, (160, 144), 3)
+    if ss == 16384:
+        assert blob == ref
+    else:   # every extra stream costs its 64 final states + length entry, give or take the words the states absorb
+        extra = ns - 2
+        assert 0 < len(blob) - len(ref) <= 260 * extra + 64
+    lens = np.frombuffer(blob[304:304 + 4 * ns], "<u4")
+    assert int(lens.sum()) == payload and np.all(lens >= 256) and np.all(lens % 2 == 0)
+    for bad in (0, 512, 3000, 32768):
+        with pytest.raises(RuntimeError):
+            c_oracle.codec_encode(lat, (0, 0), 3, stream_symbols=bad)
+    with pytest.raises(RuntimeError):
+        c_oracle.codec_encode(lat, (0, 0), 2, stream_symbols=4096)      # mode 2 has one stream length
+    hostile = bytearray(blob)
+    hostile[36:40] = struct.pack("<I", 3000)                             # a header naming a length the format does not have
+    with pytest.raises(RuntimeError):
+        c_oracle.codec_decode(bytes(hostile))
+
+
 def test_rejects_symbols_over_127_and_corruption():
     lat = _mock_latent(np.random.default_rng(3), (4, 4, 192))
     bad = lat.copy()
@@ -388,6 +419,54 @@ def test_gpu_async_pair_equals_sync_and_oracle():
     # the synchronous wrappers give the same bytes
     slots, sz = codec.encode_latents(dev, 160, 144)
     assert sz == sizes and all(torch.equal(slots[i, :sz[i]], coder.slots[i, :sz[i]]) for i in range(len(sz)))
+
+
+@gpu
+@pytest.mark.parametrize("ss", [1024, 4096, 8192, "auto"])
+def test_gpu_stream_length_parameter_equals_oracle(ss):
+    """sicn_codec_*_batch_async_sl: containers byte-identical to the oracle's at the same stream length, round trip exact; the
+    synchronous decoders read the length from the header; a decoder told another length reports the mismatch (bit 2)."""
+    import torch
+    from simple_image_compression_network_amd import codec
+    rng = np.random.default_rng(91)
+    shape = (17, 30, 192)                                   # 97920 symbols: 6 streams of 16384 ... 96 of 1024
+    lat = np.stack([_mock_latent(rng, shape, zero_frac=z) for z in (0.5, 0.1, 0.97)])
+    dev = torch.from_numpy(lat).cuda()
+    coder = codec.LatentCoder(3, *shape, image_width=480, image_height=272, stream_symbols=ss)
+    if ss == "auto":
+        assert coder.stream_symbols == codec.auto_stream_symbols(lat[0].size, 3) == 2048
+    ssv = coder.stream_symbols
+    coder.encode(dev)
+    back = torch.empty_like(dev)
+    coder.decode(back)
+    coder.check()
+    assert torch.equal(back, dev)
+    sizes = coder.sizes()
+    for i in range(3):
+        blob = coder.slots[i, :sizes[i]].cpu().numpy().tobytes()
+        assert blob == c_oracle.codec_encode(lat[i], (480, 272), 3, stream_symbols=ssv), i
+        got, info = codec.decode_latent(coder.slots[i, :sizes[i]].clone())          # synchronous single-container decoder
+        assert int(info.stream_symbols) == ssv and np.array_equal(got.cpu().numpy(), lat[i])
+    lats, infos = codec.decode_latents(coder.slots, sizes)                            # synchronous batch decoder
+    assert torch.equal(lats, dev) and all(int(f.stream_symbols) == ssv for f in infos)
+    # the oracle's containers go through the GPU decoder too
+    other = codec.LatentCoder(3, *shape, stream_symbols=ssv)
+    slots = torch.zeros_like(other.slots)
+    for i in range(3):
+        b = np.frombuffer(c_oracle.codec_encode(lat[i], (1, 2), 3, stream_symbols=ssv), np.uint8)
+        slots[i, :b.size] = torch.from_numpy(b.copy()).cuda()
+    back.zero_()
+    other.decode(back, slots=slots)
+    other.check()
+    assert torch.equal(back, dev)
+    # a decoder built for another stream length rejects the containers instead of misreading them
+    wrong = codec.LatentCoder(3, *shape, stream_symbols=16384 if ssv != 16384 else 4096)
+    w_slots = torch.zeros_like(wrong.slots)
+    k = min(w_slots.shape[1], coder.slots.shape[1])
+    w_slots[:, :k] = coder.slots[:, :k]
+    wrong.decode(back, slots=w_slots)
+    st = wrong.dec_status.cpu().numpy()
+    assert all(st[i, 0] & 4 for i in range(3)), st
 
 
 @gpu
