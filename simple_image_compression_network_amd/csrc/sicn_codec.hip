@@ -43,6 +43,13 @@ constexpr uint32_t ADLER_MOD = 65521u;
 constexpr uint32_t MAX_RANS_SYMBOLS = 0x7F000000u;
 static_assert((unsigned long long)(MAX_RANS_SYMBOLS / WSS) * WCAP < (1ull << 32), "mode 3 offsets would wrap");
 static_assert((unsigned long long)(MAX_RANS_SYMBOLS / SS) * CAP < (1ull << 32), "mode 2 offsets would wrap");
+// Asynchronous paths, small stream counts: a small image's coder time is launch latency (ten kernels of which seven were 5 us
+// bookkeeping stages), so up to this many streams per image the scans are done by the consumers themselves (every wave sums the
+// length table up to its own stream) and the statistics are per-workgroup rows instead of atomics on a block that has to be
+// cleared first: encode 6 -> 4 launches, decode 4 -> 2.
+constexpr uint32_t SELF_SCAN_MAX = 2048;
+constexpr uint32_t STAT_ROWS = 64;                 // at most this many statistics workgroups (rows) per image in row mode
+constexpr uint32_t STAT_ROW_WORDS = 256 + 4;       // hist[256], then s1, s2 as two u64
 
 struct Workspace {  // device pointers carved out of the caller's workspace
     uint32_t *hist;                // [256]
@@ -52,6 +59,7 @@ struct Workspace {  // device pointers carved out of the caller's workspace
     uint32_t *lens;                // [ns]
     uint32_t *offsets;             // [ns + 1]
     uint8_t *scratch;              // [ns][CAP]
+    uint32_t *rows;                // [STAT_ROWS][STAT_ROW_WORDS] async encode, row mode: per-workgroup histograms and checksum sums
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -67,7 +75,9 @@ size_t carve(Workspace &w, void *base, uint32_t ns, size_t scratch_per_stream)
     w.lens = (uint32_t *)(p + off); off += align_up(4 * (size_t)ns + 4, 64);
     w.offsets = (uint32_t *)(p + off); off += align_up(4 * (size_t)ns + 4, 64);
     w.scratch = p + off;
-    off += (size_t)ns * scratch_per_stream;
+    off += align_up((size_t)ns * scratch_per_stream, 64);
+    w.rows = (uint32_t *)(p + off);
+    off += (size_t)STAT_ROWS * STAT_ROW_WORDS * 4;
     return off;
 }
 
@@ -98,7 +108,8 @@ __device__ __forceinline__ const T *img_ptr(const T *p, size_t stride)
 }
 
 __global__ __launch_bounds__(256) void k_stats(const uint8_t *__restrict__ lat_, uint32_t n, uint32_t *__restrict__ hist_,
-                                               unsigned long long *__restrict__ sums_, size_t s_lat, size_t s_ws)
+                                               unsigned long long *__restrict__ sums_, size_t s_lat, size_t s_ws,
+                                               uint32_t *__restrict__ rows_ = nullptr)
 {
     const uint8_t *lat = img_ptr(lat_, s_lat);
     uint32_t *hist = img_ptr(hist_, s_ws);
@@ -150,6 +161,19 @@ __global__ __launch_bounds__(256) void k_stats(const uint8_t *__restrict__ lat_,
     uint32_t total = 0;
 #pragma unroll
     for (int c = 0; c < 8; c++) total += h[c * 257 + threadIdx.x];
+    if (rows_) {   // row mode: this workgroup's own row, plain stores (nothing to clear, no atomics on shared words)
+        __shared__ unsigned long long ws1[4], ws2[4];
+        if ((threadIdx.x & 63) == 0) { ws1[threadIdx.x >> 6] = s1; ws2[threadIdx.x >> 6] = s2 % ADLER_MOD; }
+        __syncthreads();
+        uint32_t *row = img_ptr(rows_, s_ws) + (size_t)blockIdx.x * STAT_ROW_WORDS;
+        row[threadIdx.x] = total;
+        if (threadIdx.x == 0) {
+            unsigned long long *q = (unsigned long long *)(row + 256);
+            q[0] = ws1[0] + ws1[1] + ws1[2] + ws1[3];
+            q[1] = (ws2[0] + ws2[1] + ws2[2] + ws2[3]) % ADLER_MOD;
+        }
+        return;
+    }
     if ((threadIdx.x & 63) == 0) {
         if (s1) atomicAdd(&sums[0], s1);
         if (s2) atomicAdd(&sums[1], s2 % ADLER_MOD);
@@ -293,36 +317,91 @@ __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__
                                                      const uint32_t *__restrict__ offsets_, uint32_t n, uint32_t ns,
                                                      uint8_t *__restrict__ lat_, uint32_t *__restrict__ err_, size_t s_slot,
                                                      size_t s_ws, size_t s_lat, const uint8_t *__restrict__ payload_bytes_field_,
-                                                     const uint32_t *__restrict__ meta_, unsigned long long *__restrict__ sums_, uint32_t wss)
+                                                     const uint32_t *__restrict__ meta_, unsigned long long *__restrict__ sums_, uint32_t wss,
+                                                     const uint32_t *__restrict__ self_valid_ = nullptr, uint32_t self_valid_stride = 0,
+                                                     int self = 0)
 {
+    // self != 0 (the asynchronous path up to SELF_SCAN_MAX streams): NO parse and NO scan kernel ran before this one — the
+    // wave bounds the slot itself (valid bytes, header payload field), sums the length table up to its own stream, and reports
+    // through per-stream words (err_[st], sums_[2 st .. 2 st + 1], plain stores: nothing has to be cleared beforehand);
+    // k_dec_finish_self then validates header and table and folds the per-stream words into the status.
+    const uint32_t st = blockIdx.x, lane = threadIdx.x;
     const uint8_t *payload = img_ptr(payload_, s_slot), *freq_bytes = img_ptr(freq_bytes_, s_slot);
     // header field "payload bytes" of this image's container (the host has checked it against the bytes it was
     // given): no stream may reach beyond it, whatever the untrusted length table says
     const uint8_t *pbf = img_ptr(payload_bytes_field_, s_slot);
+    uint32_t *err = img_ptr(err_, s_ws);
+    if (self) {
+        err += st;
+        const size_t fixed = SICN_CODEC_HEADER_BYTES + 256 + 4 * (size_t)ns;
+        const uint32_t valid = self_valid_ ? min(self_valid_[(size_t)blockIdx.y * self_valid_stride], (uint32_t)min(s_slot, (size_t)0xFFFFFFFFu))
+                                           : (uint32_t)min(s_slot, (size_t)0xFFFFFFFFu);
+        if (valid < fixed) {   // nothing of this slot may be read
+            if (lane == 0) *err = 1u;
+            return;
+        }
+    }
     uint32_t payload_bytes = pbf[0] | ((uint32_t)pbf[1] << 8) | ((uint32_t)pbf[2] << 16) | ((uint32_t)pbf[3] << 24);
     if (meta_) payload_bytes = min(payload_bytes, img_ptr(meta_, s_ws)[1]);   // async path: clamped by the parse stage
+    if (self) {
+        const size_t fixed = SICN_CODEC_HEADER_BYTES + 256 + 4 * (size_t)ns;
+        const uint32_t valid = self_valid_ ? min(self_valid_[(size_t)blockIdx.y * self_valid_stride], (uint32_t)min(s_slot, (size_t)0xFFFFFFFFu))
+                                           : (uint32_t)min(s_slot, (size_t)0xFFFFFFFFu);
+        if ((size_t)payload_bytes > (size_t)valid - fixed) payload_bytes = 0;   // what k_dec_parse's meta[1] says
+    }
     const uint32_t *offsets = img_ptr(offsets_, s_ws);
     uint8_t *lat = img_ptr(lat_, s_lat);
-    uint32_t *err = img_ptr(err_, s_ws);
     __shared__ RanswTab tab;
     __shared__ uint16_t freq[128];
-    __shared__ uint8_t slot[4096];
+    __shared__ __attribute__((aligned(16))) uint8_t slot[4096];
     __shared__ __attribute__((aligned(16))) uint16_t words[RING_WORDS];
-    const uint32_t st = blockIdx.x, lane = threadIdx.x;
     freq[2 * lane] = (uint16_t)(freq_bytes[4 * lane] | (freq_bytes[4 * lane + 1] << 8));
     freq[2 * lane + 1] = (uint16_t)(freq_bytes[4 * lane + 2] | (freq_bytes[4 * lane + 3] << 8));
     __syncthreads();
     ransw_build(tab, freq, (int)lane);
     __syncthreads();
-    for (int k = 0; k < 2; k++) {
-        const uint32_t t = tab.fc[2 * lane + k], f = t & 0xFFFFu, c = t >> 16;
-        for (uint32_t v = c; v < c + f && v < 4096; v++) slot[v] = (uint8_t)(2 * lane + k);
+    for (int k = 0; k < 2; k++) {   // slot[c .. c + f) = symbol: 16 bytes per store in the middle (one symbol of a ReLU latent owns
+        const uint32_t t = tab.fc[2 * lane + k], f = t & 0xFFFFu, c = t >> 16;   // half the table: 2048 byte stores by one lane
+        const uint32_t e = min(c + f, 4096u), sy = (uint32_t)(2 * lane + k);     // were a third of a short stream's decode)
+        uint32_t v = c;
+        for (; v < e && (v & 15u); v++) slot[v] = (uint8_t)sy;
+        const uint32_t pat = sy * 0x01010101u;
+        for (; v + 16 <= e; v += 16) *reinterpret_cast<uint4 *>(slot + v) = make_uint4(pat, pat, pat, pat);
+        for (; v < e; v++) slot[v] = (uint8_t)sy;
     }
     const uint32_t begin = st * wss, cnt = min(wss, n - begin), blocks = (cnt + 255) / 256;
-    const uint32_t off = offsets[st], len = offsets[st + 1] - off;
+    uint32_t off, len;
+    if (self) {   // exclusive prefix sum of the length table up to this stream, entries above the cap counting as 0 (as in k_scan)
+        const uint8_t *table = freq_bytes + 256;
+        const uint32_t cap = wstream_cap(wss);
+        auto entry = [&](uint32_t i) {
+            const uint8_t *q = table + 4 * (size_t)i;
+            const uint32_t v = q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+            return v > cap ? 0u : v;
+        };
+        uint32_t sum = 0;
+        if ((reinterpret_cast<uintptr_t>(table) & 3) == 0) {   // the usual case (slots at 4-byte multiples): one load per entry
+            const uint32_t *t32 = reinterpret_cast<const uint32_t *>(table);
+#pragma unroll 8
+            for (uint32_t i = lane; i < st; i += 64) {
+                const uint32_t v = t32[i];
+                sum += v > cap ? 0u : v;
+            }
+        } else
+            for (uint32_t i = lane; i < st; i += 64) sum += entry(i);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+        off = sum;
+        len = entry(st);
+    } else {
+        off = offsets[st];
+        len = offsets[st + 1] - off;
+    }
     if (len < 256 || (len & 1) || (off & 1) || len > wstream_cap(wss) ||
         (unsigned long long)off + len > payload_bytes) {   // streams start at even container offsets
-        if (lane == 0) atomicOr(err, 1u);
+        if (lane == 0) {
+            if (self) *err = 1u; else atomicOr(err, 1u);
+        }
         return;
     }
     const uint32_t nwords = len / 2;
@@ -372,7 +451,11 @@ __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__
             for (int k = 0; k < 4; k++)
                 if (j + k < cnt) lat[begin + j + k] = (uint8_t)(out4 >> (8 * k));
     }
-    if (bad || x != RANSW_L || wpos != nwords) atomicOr(err, 1u);
+    if (self) {   // this stream's verdict, one plain store
+        const unsigned long long any_bad = __ballot(bad || x != RANSW_L || wpos != nwords);
+        if (lane == 0) *err = any_bad ? 1u : 0u;
+    } else if (bad || x != RANSW_L || wpos != nwords)
+        atomicOr(err, 1u);
     if (sums_) {
         unsigned long long *sums = img_ptr(sums_, s_ws);
         s2 %= ADLER_MOD;
@@ -382,8 +465,13 @@ __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__
             s2 += __shfl_down(s2, d);
         }
         if (lane == 0) {
-            if (s1) atomicAdd(&sums[0], s1);
-            if (s2) atomicAdd(&sums[1], s2 % ADLER_MOD);
+            if (self) {   // per-stream partial sums: a failed stream leaves garbage here, but then the checksum is never looked at
+                sums[2 * st] = s1;
+                sums[2 * st + 1] = s2 % ADLER_MOD;
+            } else {
+                if (s1) atomicAdd(&sums[0], s1);
+                if (s2) atomicAdd(&sums[1], s2 % ADLER_MOD);
+            }
         }
     }
 }
@@ -505,6 +593,40 @@ __global__ __launch_bounds__(256) void k_compact(const uint8_t *__restrict__ scr
     for (uint32_t i = threadIdx.x; i < len; i += 256) dst[i] = src[i];
 }
 
+// The same without a scan kernel in front (asynchronous encoder, up to SELF_SCAN_MAX streams per image): every workgroup sums
+// the lengths of the streams before its own, copies its stream and writes its entry of the container's length table; the last
+// one also writes the header's payload-bytes field and the status' byte count (what k_scan did besides the offsets).
+__global__ __launch_bounds__(256) void k_compact_self(const uint8_t *__restrict__ scratch_, const uint32_t *__restrict__ lens_,
+                                                      uint8_t *__restrict__ out_, uint32_t cap, uint32_t ns, size_t s_ws, size_t s_slot,
+                                                      uint32_t *__restrict__ status_bytes_, uint32_t fixed_bytes)
+{
+    const uint8_t *scratch = img_ptr(scratch_, s_ws);
+    const uint32_t *lens = img_ptr(lens_, s_ws);
+    uint8_t *out = img_ptr(out_, s_slot);
+    uint8_t *table = out + SICN_CODEC_HEADER_BYTES + 256, *payload = table + 4 * (size_t)ns;
+    const uint32_t st = blockIdx.x, len = lens[st];
+    __shared__ uint32_t part[4];
+    uint32_t sum = 0;
+    for (uint32_t i = threadIdx.x; i < st; i += 256) sum += lens[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    const uint32_t off = part[0] + part[1] + part[2] + part[3];
+    const uint8_t *src = scratch + (size_t)st * cap + (cap - len);
+    uint8_t *dst = payload + off;
+    for (uint32_t i = threadIdx.x; i < len; i += 256) dst[i] = src[i];
+    if (threadIdx.x == 0) {
+        uint8_t *p = table + 4 * (size_t)st;
+        p[0] = (uint8_t)len; p[1] = (uint8_t)(len >> 8); p[2] = (uint8_t)(len >> 16); p[3] = (uint8_t)(len >> 24);
+        if (st == ns - 1) {
+            const uint32_t tot = off + len;
+            out[40] = (uint8_t)tot; out[41] = (uint8_t)(tot >> 8); out[42] = (uint8_t)(tot >> 16); out[43] = (uint8_t)(tot >> 24);
+            status_bytes_[2 * blockIdx.y + 1] = fixed_bytes + tot;   // sicn_codec_status.bytes
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_rans_decode(const uint8_t *__restrict__ payload, const uint8_t *__restrict__ freq_bytes,
                                                      const uint32_t *__restrict__ offsets, uint32_t n, uint32_t ns,
                                                      uint8_t *__restrict__ lat, uint32_t *__restrict__ err, uint32_t payload_bytes)
@@ -584,10 +706,11 @@ __device__ __forceinline__ void clear_stats_in_parse(uint32_t *meta, int lane)
 // Histogram -> 12-bit frequencies exactly as `normalize` / sicl_or_normalize do it (same floor, same "largest first,
 // lowest index on ties" correction walk), by one wave: lane l owns symbols 2l, 2l+1.  Then the container header and
 // frequency table.  status[0] = error flags (bit 0: symbol >= 128, bit 1: normalisation failed).
-__global__ __launch_bounds__(64) void k_enc_header(const uint32_t *__restrict__ hist_, const unsigned long long *__restrict__ sums_,
+__global__ __launch_bounds__(256) void k_enc_header(const uint32_t *__restrict__ hist_, const unsigned long long *__restrict__ sums_,
                                                    uint16_t *__restrict__ freq_, uint8_t *__restrict__ out_, uint32_t *__restrict__ status_,
                                                    uint32_t n, uint32_t ns, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c,
-                                                   uint32_t img_w, uint32_t img_h, size_t s_ws, size_t s_slot, uint32_t wss)
+                                                   uint32_t img_w, uint32_t img_h, size_t s_ws, size_t s_slot, uint32_t wss,
+                                                   const uint32_t *__restrict__ rows_ = nullptr, uint32_t n_rows = 0)
 {
     const uint32_t *hist = img_ptr(hist_, s_ws);
     const unsigned long long *sums = img_ptr(sums_, s_ws);
@@ -596,11 +719,54 @@ __global__ __launch_bounds__(64) void k_enc_header(const uint32_t *__restrict__ 
     uint32_t *status = status_ + 2 * blockIdx.y;
     const int lane = threadIdx.x;
     uint32_t err = 0;
-    if (hist[128 + lane] | hist[192 + lane]) err = 1;
+    uint32_t hh[2], hi = 0;
+    unsigned long long s1 = 0, s2 = 0;
+    if (rows_) {   // row mode (launched with 4 waves): the statistics workgroups' rows are summed here, wave w = rows w, w + 4, ..
+        const uint32_t *rows = img_ptr(rows_, s_ws);
+        __shared__ uint32_t part[4][260];
+        const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        unsigned long long p1 = 0, p2 = 0;
+#pragma unroll 4
+        for (uint32_t r = wv; r < n_rows; r += 4) {
+            const uint32_t *row = rows + (size_t)r * STAT_ROW_WORDS;
+            a0 += row[l];
+            a1 += row[64 + l];
+            a2 += row[128 + l];
+            a3 += row[192 + l];
+            if (l == 0) {
+                const unsigned long long *q = (const unsigned long long *)(row + 256);
+                p1 += q[0];
+                p2 += q[1];
+            }
+        }
+        part[wv][l] = a0; part[wv][64 + l] = a1; part[wv][128 + l] = a2; part[wv][192 + l] = a3;
+        if (l == 0) {
+            part[wv][256] = (uint32_t)p1; part[wv][257] = (uint32_t)(p1 >> 32);
+            part[wv][258] = (uint32_t)p2; part[wv][259] = (uint32_t)(p2 >> 32);
+        }
+        __syncthreads();
+        if (wv) return;
+        auto tot = [&](int i) { return part[0][i] + part[1][i] + part[2][i] + part[3][i]; };
+        hh[0] = tot(2 * lane);
+        hh[1] = tot(2 * lane + 1);
+        hi = tot(128 + lane) | tot(192 + lane);
+        for (int k = 0; k < 4; k++) {
+            s1 += part[k][256] | ((unsigned long long)part[k][257] << 32);
+            s2 += part[k][258] | ((unsigned long long)part[k][259] << 32);
+        }
+    } else {
+        hh[0] = hist[2 * lane];
+        hh[1] = hist[2 * lane + 1];
+        hi = hist[128 + lane] | hist[192 + lane];
+        s1 = sums[0];
+        s2 = sums[1];
+    }
+    if (hi) err = 1;
     uint32_t f[2];
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-        const uint32_t h = hist[2 * lane + k];
+        const uint32_t h = hh[k];
         unsigned long long v = (h && n) ? ((unsigned long long)h * 4096u) / n : 0;
         if (h && v == 0) v = 1;
         f[k] = (uint32_t)v;
@@ -631,8 +797,7 @@ __global__ __launch_bounds__(64) void k_enc_header(const uint32_t *__restrict__ 
     freq[2 * lane + 1] = (uint16_t)f[1];
     uint8_t *ft = out + SICN_CODEC_HEADER_BYTES + 4 * lane;
     ft[0] = (uint8_t)f[0]; ft[1] = (uint8_t)(f[0] >> 8); ft[2] = (uint8_t)f[1]; ft[3] = (uint8_t)(f[1] >> 8);
-    if (lane < 12) {   // header dwords 0..11 (dword 10 = payload bytes is written by k_scan)
-        const unsigned long long s1 = sums[0], s2 = sums[1];
+    if (lane < 12) {   // header dwords 0..11 (dword 10 = payload bytes is written by k_scan / k_compact_self)
         const uint32_t a = (uint32_t)((1 + s1) % ADLER_MOD), b = (uint32_t)((n % ADLER_MOD + s2) % ADLER_MOD);
         const uint32_t words[12] = {0x4C434953u /* "SICL" */, 1u | ((uint32_t)SICN_CODEC_RANSW << 16), img_w, img_h, lat_w, lat_h,
                                     lat_c, n, ns, wss, 0u, (b << 16) | a};
@@ -699,6 +864,84 @@ __global__ __launch_bounds__(64) void k_dec_finish(const uint32_t *__restrict__ 
     if (!err && ((b << 16) | a) != meta[2]) err |= 128;   // checksum (SICN_EBADMSG)
     status_[2 * blockIdx.y] = err;
     status_[2 * blockIdx.y + 1] = n;
+}
+
+// The asynchronous decoder's ONLY other kernel when the streams were decoded in self mode (k_ransw_decode, self != 0): header,
+// frequency table, payload size and length table validated here, AFTER the streams ran (they bound themselves), per-stream
+// verdicts and checksum sums folded -> status {error, n_symbols}; the same error bits as k_dec_parse + k_scan + k_dec_finish.
+__global__ __launch_bounds__(256) void k_dec_finish_self(const uint8_t *__restrict__ containers_, const uint32_t *__restrict__ valid_bytes_,
+                                                         uint32_t valid_stride, const uint32_t *__restrict__ serr_,
+                                                         const unsigned long long *__restrict__ ssum_, uint32_t *__restrict__ status_,
+                                                         uint32_t n, uint32_t ns, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c,
+                                                         size_t s_slot, size_t s_ws, uint32_t wss)
+{
+    const uint8_t *c = img_ptr(containers_, s_slot);
+    const uint32_t *serr = img_ptr(serr_, s_ws);
+    const unsigned long long *ssum = img_ptr(ssum_, s_ws);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t valid = valid_bytes_ ? min(valid_bytes_[(size_t)blockIdx.y * valid_stride], (uint32_t)min(s_slot, (size_t)0xFFFFFFFFu))
+                                        : (uint32_t)min(s_slot, (size_t)0xFFFFFFFFu);
+    const size_t fixed = SICN_CODEC_HEADER_BYTES + 256 + 4 * (size_t)ns;
+    __shared__ uint32_t r_err, r_tab;
+    __shared__ unsigned long long r_s1, r_s2;
+    if (tid == 0) { r_err = 0; r_tab = 0; r_s1 = 0; r_s2 = 0; }
+    __syncthreads();
+    if (valid < fixed) {   // nothing of this slot was read: bit 8 + bit 2, and bit 5 for the streams that all refused it
+        if (tid == 0) {
+            status_[2 * blockIdx.y] = 0x104u | (ns ? 32u : 0u);
+            status_[2 * blockIdx.y + 1] = n;
+        }
+        return;
+    }
+    auto rd32 = [&](size_t o) { return c[o] | ((uint32_t)c[o + 1] << 8) | ((uint32_t)c[o + 2] << 16) | ((uint32_t)c[o + 3] << 24); };
+    uint32_t err = 0;
+    if (tid < 64) {   // wave 0: the checks of k_dec_parse
+        const uint32_t expect[10] = {0x4C434953u, 1u | ((uint32_t)SICN_CODEC_RANSW << 16), 0, 0, lat_w, lat_h, lat_c, n, ns, wss};
+        if (lane < 10 && lane != 2 && lane != 3 && rd32(4 * lane) != expect[lane]) err = 4;
+        uint32_t fsum = c[SICN_CODEC_HEADER_BYTES + 4 * lane] + ((uint32_t)c[SICN_CODEC_HEADER_BYTES + 4 * lane + 1] << 8) +
+                        c[SICN_CODEC_HEADER_BYTES + 4 * lane + 2] + ((uint32_t)c[SICN_CODEC_HEADER_BYTES + 4 * lane + 3] << 8);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) fsum += __shfl_xor((int)fsum, d);
+        if (n && fsum != 4096) err |= 8;
+    }
+    const uint32_t pb = rd32(40);
+    const bool pb_bad = (size_t)pb > (size_t)valid - fixed;
+    if (tid == 0 && pb_bad) err |= 16;
+    const uint32_t bound = pb_bad ? 0u : pb;
+    // length table: entries above the cap are an error and count as 0 (k_scan); the per-stream verdicts; the checksum sums
+    const uint32_t cap = wstream_cap(wss);
+    uint32_t tab = 0;
+    unsigned long long s1 = 0, s2 = 0;
+    for (uint32_t i = tid; i < ns; i += 256) {
+        uint32_t v = rd32(SICN_CODEC_HEADER_BYTES + 256 + 4 * (size_t)i);
+        if (v > cap) { err |= 32; v = 0; }
+        tab += v;
+        if (serr[i]) err |= 32;
+        else { s1 += ssum[2 * i]; s2 += ssum[2 * i + 1]; }
+    }
+    s2 %= ADLER_MOD;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        err |= (uint32_t)__shfl_xor((int)err, d);
+        tab += (uint32_t)__shfl_xor((int)tab, d);
+        s1 += __shfl_xor(s1, d);
+        s2 += __shfl_xor(s2, d);
+    }
+    if (lane == 0) {
+        if (err) atomicOr(&r_err, err);
+        if (tab) atomicAdd(&r_tab, tab);
+        if (s1) atomicAdd(&r_s1, s1);
+        if (s2) atomicAdd(&r_s2, s2 % ADLER_MOD);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t e = r_err;
+        if (r_tab != bound) e |= 64;           // the length table does not add up to the payload
+        const uint32_t a = (uint32_t)((1 + r_s1) % ADLER_MOD), b = (uint32_t)((n % ADLER_MOD + r_s2) % ADLER_MOD);
+        if (!e && ((b << 16) | a) != rd32(44)) e |= 128;   // checksum (SICN_EBADMSG)
+        status_[2 * blockIdx.y] = e;
+        status_[2 * blockIdx.y + 1] = n;
+    }
 }
 
 // ---- host helpers --------------------------------------------------------------------------------
@@ -1039,6 +1282,18 @@ extern "C" int sicn_codec_encode_batch_async_sl(const uint8_t *latents, uint32_t
     uint32_t *status = (uint32_t *)status_dev;
     uint8_t *table = out + SICN_CODEC_HEADER_BYTES + 256, *payload = table + 4 * (size_t)ns;
     const uint32_t fixed = (uint32_t)(SICN_CODEC_HEADER_BYTES + 256 + 4 * (size_t)ns);
+    if (ns && ns <= SELF_SCAN_MAX) {
+        // four launches: statistics in rows (no clear, no atomics) -> header + table -> streams -> compaction with its own scan
+        const uint32_t n_rows = std::min(std::max(n / 16384u, 1u), STAT_ROWS);
+        hipLaunchKernelGGL(k_stats, dim3(n_rows, n_images), dim3(256), 0, stream, latents, n, w.hist, w.sums, (size_t)n, ws1, w.rows);
+        hipLaunchKernelGGL(k_enc_header, dim3(1, n_images), dim3(256), 0, stream, w.hist, w.sums, w.freq, out, status, n, ns, lat_w,
+                           lat_h, lat_c, img_w, img_h, ws1, slot_bytes, wss, (const uint32_t *)w.rows, n_rows);
+        hipLaunchKernelGGL(k_ransw_encode, dim3(ns, n_images), dim3(64), 0, stream, latents, n, ns, w.freq, w.scratch, w.lens,
+                           (size_t)n, ws1, wss);
+        hipLaunchKernelGGL(k_compact_self, dim3(ns, n_images), dim3(256), 0, stream, w.scratch, w.lens, out, wcap, ns, ws1, slot_bytes,
+                           status, fixed);
+        return hipGetLastError() == hipSuccess ? SICN_OK : SICN_ENODEV;
+    }
     hipLaunchKernelGGL(k_clear_stats, dim3(1, n_images), dim3(64), 0, stream, w.hist, ws1);
     if (n)
         hipLaunchKernelGGL(k_stats, dim3(stats_blocks(n, n_images), n_images), dim3(256), 0, stream, latents, n, w.hist,
@@ -1082,6 +1337,19 @@ extern "C" int sicn_codec_decode_batch_async_sl(const uint8_t *containers, size_
     Workspace w;
     carve(w, workspace, ns, 0);
     const uint8_t *freq_bytes = containers + SICN_CODEC_HEADER_BYTES, *table = freq_bytes + 256, *payload = table + 4 * (size_t)ns;
+    if (ns <= SELF_SCAN_MAX) {
+        // two launches instead of four: the streams bound and place themselves (self mode), the finish kernel validates header
+        // and table and folds the per-stream verdicts / checksum sums (a small image's decode is mostly launch latency)
+        uint32_t *serr = w.lens;                                           // [ns]
+        unsigned long long *ssum = (unsigned long long *)w.scratch;        // [2 ns]; the scratch slots (>= 2304 B each) are idle in a decode
+        const uint32_t *vb = valid_dev_or_null ? &valid_dev_or_null->bytes : (const uint32_t *)nullptr;
+        if (ns)
+            hipLaunchKernelGGL(k_ransw_decode, dim3(ns, n_images), dim3(64), 0, stream, payload, freq_bytes, (const uint32_t *)nullptr, n, ns,
+                               latents, serr, slot_bytes, ws1, latent_stride, containers + 40, (const uint32_t *)nullptr, ssum, wss, vb, 2u, 1);
+        hipLaunchKernelGGL(k_dec_finish_self, dim3(1, n_images), dim3(256), 0, stream, containers, vb, 2u, serr, ssum, (uint32_t *)status_dev,
+                           n, ns, lat_w, lat_h, lat_c, slot_bytes, ws1, wss);
+        return hipGetLastError() == hipSuccess ? SICN_OK : SICN_ENODEV;
+    }
     hipLaunchKernelGGL(k_dec_parse, dim3(1, n_images), dim3(64), 0, stream, containers,
                        valid_dev_or_null ? &valid_dev_or_null->bytes : (const uint32_t *)nullptr, 2u, w.meta, n, ns, lat_w, lat_h,
                        lat_c, slot_bytes, ws1, wss);

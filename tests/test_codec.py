@@ -470,6 +470,32 @@ def test_gpu_stream_length_parameter_equals_oracle(ss):
 
 
 @gpu
+def test_gpu_async_decode_with_many_streams_takes_the_scan_path():
+    """More than 2048 streams per image (here 2160 of 1024 symbols): the asynchronous decoder goes back to its four-kernel form
+    (parse, scan, streams, finish) — up to 2048 every wave sums the length table itself.  Same bytes, same verdicts."""
+    import torch
+    from simple_image_compression_network_amd import _lib, codec
+    shape = (64, 180, 192)
+    lat = _mock_latent(np.random.default_rng(93), (2,) + shape)
+    dev = torch.from_numpy(lat).cuda()
+    coder = codec.LatentCoder(2, *shape, stream_symbols=1024)
+    coder.encode(dev)
+    back = torch.empty_like(dev)
+    coder.decode(back)
+    coder.check()
+    assert torch.equal(back, dev)
+    sizes = coder.sizes()
+    assert coder.slots[1, :sizes[1]].cpu().numpy().tobytes() == c_oracle.codec_encode(lat[1], (0, 0), 3, stream_symbols=1024)
+    bad = coder.slots.clone()
+    bad[0, 48 + 256 + 4 * 2100 + 2] ^= 0x7F                 # length entry of stream 2100 of image 0: far above the cap
+    coder.decode(back, slots=bad)
+    st = coder.dec_status.cpu().numpy()
+    assert st[0, 0] & 32 and st[1, 0] == 0, st
+    with pytest.raises(_lib.SicnError):
+        coder.check()
+
+
+@gpu
 def test_gpu_async_reports_errors_in_device_status():
     import torch
     from simple_image_compression_network_amd import _lib, codec
