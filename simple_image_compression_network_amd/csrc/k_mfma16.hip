@@ -402,7 +402,14 @@ static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint
     // where every CU gets at least WIDE_MIN_TILES tiles; sicn_options.wave_tile = 128 forces it, 64 forbids it
     if (wide_supported(g) && o.tile_x != 16) {
         const long tiles_w = (long)((MW + 31) / 32) * ((MH + 15) / 16) * n_images;
-        if (o.wave_tile == 128 || (o.wave_tile == 0 && o.prefetch == 0 && tiles_w >= 256L * WIDE_MIN_TILES))
+        // automatic: from WIDE_MIN_TILES tiles per CU on, the conv already from 3.5 rounds of 256 tiles when the last round is at
+        // least 90 % full (measured r03, tools/ab_options.py, 1080p x 4 and 4K x 1 = 1020 tiles: layer 1 131 - 140 against
+        // 144 - 149 us; at 255 / 510 tiles the wide conv loses, 44 / 39 and 70 / 68 us; the deconv is a wash below 1024: 45 / 47,
+        // 75 / 75, 146 / 142 us)
+        const long rounds = (tiles_w + 255) / 256;
+        const bool full_rounds = tiles_w * 10 >= rounds * 256 * 9;
+        const bool automatic = tiles_w >= 256L * WIDE_MIN_TILES || (!DECONV && full_rounds && 2 * tiles_w >= 7 * 256);
+        if (o.wave_tile == 128 || (o.wave_tile == 0 && o.prefetch == 0 && automatic))
             return launch_wide(g, w, in, out, n_images, stream, in_layout, out_layout, relu, o.persistent_grid);
     }
     const long tiles32 = (long)((MW + 31) / 32) * ((MH + TILE_Y - 1) / TILE_Y) * n_images;
