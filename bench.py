@@ -445,7 +445,7 @@ def main():
                 "note": "latency of ONE image: each rank computes a band with 64 rows of recomputed halo, one all-gather of the kept rows"}
 
     strong = banded = None
-    if world > 1 and not args.headline_only:
+    if (world > 1 or os.environ.get("SICN_BENCH_FORCE_DIST") == "1") and not args.headline_only:
         strong = secondary("strong_scaling", strong_leg)
         banded = secondary("banded", banded_leg)
     if rank != 0:

@@ -13,6 +13,8 @@ reconstruction (and of the latent) are all-gathered.
 """
 from __future__ import annotations
 
+import os
+
 import zlib
 from typing import Callable, Dict, List, Sequence
 
@@ -136,7 +138,9 @@ def forward_banded(compute: Callable[[np.ndarray], Sequence[np.ndarray]], image:
     import torch
     import torch.distributed as dist
 
-    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    # SICN_FORCE_COLLECTIVES=1: take the collective path with ONE rank too (a 1-GPU box can then run the RCCL all-gather code)
+    distributed = dist.is_available() and dist.is_initialized() and (
+        dist.get_world_size(group) > 1 or os.environ.get("SICN_FORCE_COLLECTIVES") == "1")
     if distributed:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         n_bands = world
@@ -238,7 +242,9 @@ def forward_banded_tensors(compute, image, n_bands: int = 0, group=None):
     import torch
     import torch.distributed as dist
 
-    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    # SICN_FORCE_COLLECTIVES=1: take the collective path with ONE rank too (a 1-GPU box can then run the RCCL all-gather code)
+    distributed = dist.is_available() and dist.is_initialized() and (
+        dist.get_world_size(group) > 1 or os.environ.get("SICN_FORCE_COLLECTIVES") == "1")
     if distributed:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         n_bands = world

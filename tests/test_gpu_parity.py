@@ -571,10 +571,14 @@ def test_bench_rccl_code_path_single_rank():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29547", str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
            "--no-hyperprior", "--width", "512", "--height", "256", "--images-per-gpu", "2"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT), env=dict(os.environ, SICN_BENCH_FORCE_DIST="1"))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(ROOT),
+                       env=dict(os.environ, SICN_BENCH_FORCE_DIST="1", SICN_FORCE_COLLECTIVES="1"))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert "nccl" in d["config"]["collectives"] and d["value"] > 0 and d["with_coder"]["round_trip_exact"] is True
+    # the N > 1 secondaries ran too, with the band split's all-gather going through RCCL on device tensors (one band here)
+    assert d["strong_scaling"]["images_per_gpu"] == 64 and d["strong_scaling"]["value"] > 0
+    assert d["banded"]["bands"] == 1 and d["banded"]["equals_one_gpu_bytes"] is True
     assert not [k for k, v in d.items() if isinstance(v, dict) and "error" in v], d
 
 
