@@ -105,7 +105,9 @@ class HyperpriorCodec:
         self.s_full = torch.empty((n,) + ds[-1].out_shape, **u8)     # 2 * ceil(./2) >= the latent's size: cropped below
         self.s = torch.empty_like(self.y)
         self.y_hat = torch.empty_like(self.y)
-        self.z_coder = codec.LatentCoder(n, zh, zw, zc, width, height, device=self.device)
+        # the hyper-latent is small (4K: 261 k symbols = 16 streams of 16384 per image): the longest stream length that still
+        # fills the chip (codec.auto_stream_symbols; the container records it, decoders built like this one pick the same)
+        self.z_coder = codec.LatentCoder(n, zh, zw, zc, width, height, device=self.device, stream_symbols="auto")
         self.y_coder = codec.ContextCoder(n, lat_h, lat_w, lat_c, width, height, device=self.device)
         for net in (self.main, self.h_a, self.h_s):
             net.workspace(n)

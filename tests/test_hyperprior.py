@@ -65,7 +65,7 @@ def _pipeline_against_oracle(size, use_gdn, n):
         for (wt, bt) in hc.ha_np:
             z = _cpu_layer(z, wt, bt, 0)
         assert np.array_equal(hc.z[i].cpu().numpy(), z), "hyper-latent"
-        zblob = c_oracle.codec_encode(z, (w, h), 3)
+        zblob = c_oracle.codec_encode(z, (w, h), 3, stream_symbols=hc.z_coder.stream_symbols)
         assert hc.z_coder.slots[i, :zs[i]].cpu().numpy().tobytes() == zblob
         s = z
         for (wt, bt) in hc.hs_np:
