@@ -17,6 +17,8 @@
 #include <vector>
 
 #include "k_common.hpp"
+#include <type_traits>
+
 #include "sicn_gdn_internal.h"
 
 namespace sicn {
@@ -54,12 +56,16 @@ __device__ __forceinline__ uint32_t gdn_sqrt8(uint32_t n)
 // The same root for n < 2^29 (the MFMA kernels: C <= 192), where the estimate is within 0.89 of the true value (cvt 2^-25 +
 // v_sqrt_f32 2^-23 relative, of at most 5.93e6): with q = floor(t~ + 0.95) the floor is q - 2, q - 1 or q — TWO tests instead of
 // four: r = q - 2 + [(q - 1)^2 <= N] + [q^2 <= N], i.e. with d = N - q^2: [1 - 2 q <= d] + [0 <= d].
+// NZ: n >= 1 is known (the kernels: beta >= 1), so q >= 256 and the guard for n = 0 goes.  The two tests are taken as sign bits:
+// [d >= 0] - 1 = d >> 31 and [d + 2 q - 1 >= 0] - 1 = (d + 2 q - 1) >> 31 (arithmetic), r = q + both — 8 integer instructions.
+template <bool NZ = false>
 __device__ __forceinline__ uint32_t gdn_sqrt8_narrow(uint32_t n)
 {
     uint32_t q = (uint32_t)(256.0f * __fsqrt_rn((float)n) + 0.95f);
-    q = max(q, 2u);
+    if (!NZ) q = max(q, 2u);
     const int d = (int)((n << 16) - __umul24(q, q));
-    return q - 2 + (1 - (int)(2u * q) <= d ? 1u : 0u) + (0 <= d ? 1u : 0u);
+    const int e = (int)(2u * q) + d - 1;
+    return q + (uint32_t)(d >> 31) + (uint32_t)(e >> 31);
 }
 
 // exact references for the self-test: integer bisection, as in oracle/sicn_gdn_oracle.c
@@ -89,7 +95,8 @@ __global__ __launch_bounds__(256) void k_gdn_selftest(uint32_t n_begin, unsigned
     for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * 256) {
         const uint32_t n = n_begin + (uint32_t)i;
         if (!inverse && n == 0) continue;   // GDN: n >= 1 (beta >= 1)
-        const uint32_t fast = inverse == 2 ? gdn_sqrt8_narrow(n) : inverse ? gdn_sqrt8(n) : gdn_rsqrt16(n);
+        // inverse == 2: the narrow root exactly as the kernels call it (n >= 1: the NZ form; n = 0 only exists for the guarded form)
+        const uint32_t fast = inverse == 2 ? (n ? gdn_sqrt8_narrow<true>(n) : gdn_sqrt8_narrow<false>(n)) : inverse ? gdn_sqrt8(n) : gdn_rsqrt16(n);
         const uint32_t slow = inverse ? gdn_sqrt8_slow(n) : gdn_rsqrt16_slow(n);
         mine += fast != slow;
     }
@@ -100,15 +107,46 @@ __global__ __launch_bounds__(256) void k_gdn_selftest(uint32_t n_begin, unsigned
 template <bool INVERSE, bool NARROW = false>
 __device__ __forceinline__ int gdn_out(int x, uint32_t n, int sh)
 {
-    const uint32_t r = INVERSE ? (NARROW ? gdn_sqrt8_narrow(n) : gdn_sqrt8(n)) : gdn_rsqrt16(n);
+    const uint32_t r = INVERSE ? (NARROW ? gdn_sqrt8_narrow<true>(n) : gdn_sqrt8(n)) : gdn_rsqrt16(n);   // NARROW = the MFMA kernels: n >= beta >= 1
     int t;
-    if (NARROW)   // spelled out: left to itself hipcc folds the add into a quarter-rate v_mad_u64_u32
-        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(t) : "v"(x), "v"(r), "v"(1 << (sh - 1)));
+    if (NARROW)   // v_mad_i32_i24 through the builtin (left to itself hipcc folds x * r + c into a quarter-rate v_mad_u64_u32; an asm
+        t = __mul24(x, (int)r) + (1 << (sh - 1));   // statement here had its output placed on an in-flight MFMA operand: isa_hazards.py)
     else
         t = x * (int)r + (1 << (sh - 1));
     t >>= sh;   // |x r| < 2^30; arithmetic shift
     return max(-128, min(127, t));
 }
+
+// Byte K of `dst` = the low byte of an ALU result, the other bytes kept (K = 0: cleared) — SDWA destination select.  The split
+// x^2 = 128 hi + lo and the output bytes are packed this way: one instruction per byte instead of shift + mask + or (r03: the
+// pass is VALU-bound; 29 -> 24 instructions per element).
+// Byte 0 is NOT written by an asm statement: a fresh asm output may be given the register of an MFMA operand that is still in
+// flight, and hipcc's hazard recogniser does not look inside asm (tools/isa_hazards.py found exactly that); the first write is
+// an ordinary instruction the compiler spaces correctly, bytes 1 - 3 then go into a register that is already live.
+#define SICN_SDWA_BYTE(K, OPC, TAIL)                                                                                  \
+    static_assert(K >= 1 && K <= 3, "byte 0 is written by the caller with an ordinary instruction");                  \
+    if constexpr (K == 1)                                                                                             \
+        asm(OPC " dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE " TAIL : "+v"(dst) : "v"(a), "v"(b));                     \
+    else if constexpr (K == 2)                                                                                        \
+        asm(OPC " dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE " TAIL : "+v"(dst) : "v"(a), "v"(b));                     \
+    else                                                                                                              \
+        asm(OPC " dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE " TAIL : "+v"(dst) : "v"(a), "v"(b));
+template <int K>
+__device__ __forceinline__ void sdwa_put_shr(int &dst, uint32_t a /* shift */, uint32_t b /* value */)   // byte K = (b >> a) & 255
+{
+    SICN_SDWA_BYTE(K, "v_lshrrev_b32_sdwa %0, %1, %2", "src0_sel:DWORD src1_sel:DWORD")
+}
+template <int K>
+__device__ __forceinline__ void sdwa_put_and(int &dst, uint32_t a /* mask */, uint32_t b /* value */)    // byte K = (a & b) & 255
+{
+    SICN_SDWA_BYTE(K, "v_and_b32_sdwa %0, %1, %2", "src0_sel:DWORD src1_sel:DWORD")
+}
+template <int K>
+__device__ __forceinline__ void sdwa_put_or(int &dst, uint32_t a /* 0 */, uint32_t b /* value */)        // byte K = low byte of b
+{
+    SICN_SDWA_BYTE(K, "v_or_b32_sdwa %0, %1, %2", "src0_sel:DWORD src1_sel:BYTE_0")
+}
+#undef SICN_SDWA_BYTE
 
 struct GdnMap {   // byte offset of 16-byte chunk k of position p: (p / P) * plane + (p % P) * pix + (k >> 1) * grp + (k & 1) * 16
     uint32_t P, plane, pix, grp;
@@ -170,21 +208,32 @@ __global__ __launch_bounds__(256, 4) void k_gdn(uint8_t *__restrict__ data, cons
 #pragma unroll
                 for (int J = 0; J < NJ; J++) xn[J] = __builtin_amdgcn_raw_buffer_load_b128(rs, chunk_off(base_n, ok_n, J), 0, 0);
             }
+            uint32_t c7 = 7u, c127 = 127u, c0 = 0u;
+            asm volatile("" : "+v"(c7), "+v"(c127), "+v"(c0));   // SDWA takes no literals: the three constants live in registers
 #pragma unroll
             for (int J = 0; J < NJ; J++) {
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
-                    uint32_t h = 0, l = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; b++) {
+                    int h, l;
+                    auto one = [&](auto kc) {
+                        constexpr int b = decltype(kc)::value;
                         int v = (int)(int8_t)((uint32_t)xf[J][d] >> (8 * b));
                         v = max(v, -127);
-                        const uint32_t sq = (uint32_t)(v * v);
-                        h |= (sq >> 7) << (8 * b);
-                        l |= (sq & 127u) << (8 * b);
-                    }
-                    hf[J][d] = (int)h;
-                    lf[J][d] = (int)l;
+                        const uint32_t sq = (uint32_t)(v * v);   // <= 16129: hi = sq >> 7 <= 126 and lo = sq & 127 are bytes
+                        if constexpr (b == 0) {
+                            h = (int)(sq >> 7);
+                            l = (int)(sq & 127u);
+                        } else {
+                            sdwa_put_shr<b>(h, c7, sq);
+                            sdwa_put_and<b>(l, c127, sq);
+                        }
+                    };
+                    one(std::integral_constant<int, 0>{});
+                    one(std::integral_constant<int, 1>{});
+                    one(std::integral_constant<int, 2>{});
+                    one(std::integral_constant<int, 3>{});
+                    hf[J][d] = h;
+                    lf[J][d] = l;
                 }
             }
             // Tile j's 4 accumulators per lane are 4 consecutive channels: register r of tile j = channel
@@ -194,15 +243,22 @@ __global__ __launch_bounds__(256, 4) void k_gdn(uint8_t *__restrict__ data, cons
             v4i y[NJ];
             auto finish = [&](const v4i &a, int j) {
                 const int J = j >> 2, d = j & 3;
-                uint32_t packed = 0;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
+                int packed;
+                auto one = [&](auto kc) {
+                    constexpr int r = decltype(kc)::value;
                     int x = (int)(int8_t)((uint32_t)xf[J][d] >> (8 * r));
                     x = max(x, -127);
                     const int t = gdn_out<INVERSE, true>(x, (uint32_t)a[r], sh);
-                    packed |= ((uint32_t)t & 255u) << (8 * r);
-                }
-                y[J][d] = (int)packed;
+                    if constexpr (r == 0)
+                        packed = t & 255;
+                    else
+                        sdwa_put_or<r>(packed, c0, (uint32_t)t);
+                };
+                one(std::integral_constant<int, 0>{});
+                one(std::integral_constant<int, 1>{});
+                one(std::integral_constant<int, 2>{});
+                one(std::integral_constant<int, 3>{});
+                y[J][d] = packed;
             };
             v4i a_prev = {0, 0, 0, 0};
 #pragma unroll
