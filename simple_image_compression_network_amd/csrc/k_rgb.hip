@@ -325,6 +325,12 @@ __device__ __forceinline__ void l7_load_rows(uint8_t *patch, uint8_t *scratch, c
     }
 }
 
+#ifdef SICN_EXP_L7_STAMP   // diagnostic build: cycles per phase of a step, summed over all waves and steps (s_memtime)
+__device__ unsigned long long g_l7_stamp[8];
+#define L7_T(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[i] += t_ - tp_; tp_ = t_; }
+#else
+#define L7_T(i)
+#endif
 __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                const int8_t *__restrict__ w_l7,
                                                const int8_t *__restrict__ bias, int IW, int IH, int OW,
@@ -392,12 +398,25 @@ __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ 
     block_barrier();
 
     int base = 0;                          // (144 t) mod ring: ring slot of window row 4t, column 0
+#ifdef SICN_EXP_L7_STAMP
+    unsigned long long st_[6] = {0, 0, 0, 0, 0, 0}, tp_ = __builtin_amdgcn_s_memtime();
+#endif
     for (int s = s_begin; s < s_end; s++) {
         const int Y = 4 * s;               // first input row of this step
         // always issued (rows past the chunk are zero fill): the counted waits below rely on it
         l7_load_rows<5>(patch, scratch, in_img, in_img_bytes, w, lane, L7_STEP_PIECES, ynext, 0, iy_max, pnext, X0, IW, tm);
         ynext += L7_ROWS;
+        L7_T(0)   // the row requests (address arithmetic + issue)
 
+#ifdef SICN_EXP_L7_DMA_ONLY   // timing experiment (wrong bytes): the row requests, their counted wait and the barrier, nothing else
+        wait_vmcnt<5 * (L7_AHEAD - 1)>();
+        block_barrier();
+        base += L7_ROWS * L7_PITCH;
+        base = base >= L7_RING_POS ? base - L7_RING_POS : base;
+        pnext += L7_STEP_PIECES;
+        pnext = pnext >= L7_RING_PIECES ? pnext - L7_RING_PIECES : pnext;
+        continue;
+#endif
         v4i acc[2];
         acc[0] = acc[1] = v4i{b0, b1, b2, 0};  // C row 4*kg + r = phase kg, channel r
 #pragma unroll
@@ -415,6 +434,8 @@ __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ 
 #endif
             }
         }
+        asm volatile("" :: "v"(acc[0]), "v"(acc[1]));
+        L7_T(1)   // fragment reads + MFMAs issued
         // ---- epilogue ----------------------------------------------------------------------
         const int gy = Y + w;
         if (fast_rows) {
@@ -443,6 +464,7 @@ __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ 
                 __builtin_amdgcn_raw_buffer_store_b32(v, ro, off, 0, 0);
 #endif
             }
+            L7_T(2)   // pack, staging, stores issued
             // leave in flight: this step's 2 stores and the AHEAD-1 younger row blocks (5 loads + 2 stores each)
 #if SICN_EXP_L7_STORE == 1
             wait_vmcnt<5 * (L7_AHEAD - 1)>();
@@ -463,16 +485,32 @@ __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ 
             }
             wait_vmcnt<0>();
         }
+        L7_T(3)   // counted wait for the next rows
 #ifndef SICN_EXP_L7_NO_BARRIER   // timing experiment only (races)
         block_barrier();   // next rows landed for every wave, this step's rows are free
 #endif
+        L7_T(4)   // barrier
         base += L7_ROWS * L7_PITCH;
         base = base >= L7_RING_POS ? base - L7_RING_POS : base;
         pnext += L7_STEP_PIECES;
         pnext = pnext >= L7_RING_PIECES ? pnext - L7_RING_PIECES : pnext;
     }
     wait_vmcnt<0>();   // the zero-fill tail of the prefetch must land before the LDS is released
+#ifdef SICN_EXP_L7_STAMP
+    if (lane == 0) {
+        for (int i = 0; i < 5; i++) atomicAdd(&g_l7_stamp[i], st_[i]);
+        atomicAdd(&g_l7_stamp[5], (unsigned long long)(s_end - s_begin));
+    }
+#endif
 }
+#ifdef SICN_EXP_L7_STAMP
+extern "C" int sicn_debug_l7_stamps(unsigned long long *out8)   // reads and clears the sums
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_l7_stamp), sizeof z) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_l7_stamp), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
 
 size_t l7_bytes(int cin) { return (size_t)18 * 16 * 64 * (cin / 128); }
 
