@@ -413,7 +413,10 @@ static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint
             return launch_wide(g, w, in, out, n_images, stream, in_layout, out_layout, relu, o.persistent_grid);
     }
     const long tiles32 = (long)((MW + 31) / 32) * ((MH + TILE_Y - 1) / TILE_Y) * n_images;
-    bool narrow = minw16(NQ, NT16, 32) == 1 || tiles32 < 2 * 256;
+    // 8 x 32 tiles from about 0.8 of one residency (2 workgroups x 256 CUs) on: below that the 8 x 16 tiles' second, partly filled
+    // round is still cheaper; measured r03 on one image of 1440 x 810 ... 1920 x 1080 (312 ... 506 tiles of 8 x 32), layer 1 / 6:
+    // 8 x 16 tiles 30 31 | 38 39 39 / 39 40 | 47 47 46 us, 8 x 32 tiles 35 35 | 35 36 36 / 40 40 | 41 42 41 us (the bar at 434 tiles)
+    bool narrow = minw16(NQ, NT16, 32) == 1 || tiles32 < 416;
     if (o.tile_x == 16) narrow = true;
     if (o.tile_x == 32) narrow = false;
     // the software-pipelined form of the same kernels (k_mfma16p.hip) is the default wherever it exists
