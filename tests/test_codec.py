@@ -113,6 +113,20 @@ def test_stream_length_is_an_encoder_parameter(ss):
         c_oracle.codec_decode(bytes(hostile))
 
 
+def test_auto_stream_length_policy():
+    """codec.auto_stream_symbols: the longest admissible stream that still gives the chip about two waves per CU."""
+    from simple_image_compression_network_amd import codec
+    n4k, n1080, nz = 135 * 240 * 192, 68 * 120 * 192, 34 * 60 * 128
+    assert codec.auto_stream_symbols(n4k, 8) == 16384          # 8 x 4K latents: 3040 streams of the default length
+    assert codec.auto_stream_symbols(n4k, 1) == 8192           # one 4K latent: 380 streams of 16384 would half-fill the chip
+    assert codec.auto_stream_symbols(n1080, 1) == 2048         # one 1080p latent: 765 streams
+    assert codec.auto_stream_symbols(nz, 8) == 4096            # the hyperprior's hyper-latents of 8 x 4K
+    assert codec.auto_stream_symbols(1000, 1) == 1024 and codec.auto_stream_symbols(0, 1) == 1024
+    for n in (1, 12345, n1080, n4k):
+        for k in (1, 3, 8):
+            assert codec.auto_stream_symbols(n, k) in (1024, 2048, 4096, 8192, 16384)
+
+
 def test_rejects_symbols_over_127_and_corruption():
     lat = _mock_latent(np.random.default_rng(3), (4, 4, 192))
     bad = lat.copy()
