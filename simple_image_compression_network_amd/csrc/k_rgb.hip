@@ -542,10 +542,12 @@ hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
     if ((size_t)g.OH * g.OW * 3 >= (size_t)OOB) return hipErrorInvalidValue;   // buffer-descriptor stores
     const int tiles_x = (g.IW + TILE_X - 1) / TILE_X, steps_y = (g.IH + L7_ROWS - 1) / L7_ROWS;
     int y_chunks = o.strip_chunks;
-    // about 640 workgroups in all (three fit a CU: a little under one residency, so there is no tail round) — measured
+    // about 512 workgroups in all (two per CU; three would fit) — measured
     // r02 (tools/strip_sweep.py): 1080p x 1 best at 16 - 24 chunks of 30 strips, x 4 at 4 - 6 of 120, 4K x 8 at 1 of 480;
     // every extra chunk re-fetches six halo rows and re-loads the 18 KB of weights
-    if (y_chunks <= 0) y_chunks = (640 + tiles_x * n_images / 2) / (tiles_x * n_images);
+    // (r03, re-measured on one 1080p image, 30 strips: 13 / 15 / 17 / 19 / 21 / 25 chunks -> 23 / 22 / 19 / 24 / 23 / 21 us: the best
+    // cut is the one that stays just under TWO workgroups per CU, 510 of 512; the 640 of round 2 was the middle of a flat region)
+    if (y_chunks <= 0) y_chunks = 512 / (tiles_x * n_images);
     y_chunks = y_chunks < 1 ? 1 : (y_chunks > steps_y ? steps_y : y_chunks);
     const size_t lds = 2 * L7_REGION + 4 * L7_STAGE + 1024;
     hipError_t e = hipFuncSetAttribute((const void *)k_l7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
