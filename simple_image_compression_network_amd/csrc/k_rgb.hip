@@ -426,7 +426,16 @@ __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ 
                 uint32_t slot = (uint32_t)base + fa[tap] + 16u * c;
                 slot = min(slot, slot - (uint32_t)L7_RING_POS);   // one wrap at most
                 const uint32_t addr = slot * 64u + fs[tap];
-#ifndef SICN_EXP_L7_NO_MFMA
+#if defined(SICN_EXP_L7_READS_ONLY)   // timing experiments (wrong bytes): the fragment reads without the MFMAs ...
+                const v4i p0 = *(const v4i *)(patch + addr);
+                const v4i p1 = *(const v4i *)(patch + (addr ^ 32u));
+                acc[c][0] ^= p0[0] ^ p1[3];
+                acc[c][1] ^= p0[1] ^ p1[2];
+#elif defined(SICN_EXP_L7_MFMA_ONLY)    // ... and the MFMAs without the fragment reads
+                acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[tap * 2 + 0], wf[(tap * 2 + 5) % 18], acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[tap * 2 + 1], wf[(tap * 2 + 7) % 18], acc[c], 0, 0, 0);
+                (void)addr;
+#elif !defined(SICN_EXP_L7_NO_MFMA)
                 const v4i p0 = *(const v4i *)(patch + addr);
                 const v4i p1 = *(const v4i *)(patch + (addr ^ 32u));   // channels 64..127: c2 ^ 2
                 acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[tap * 2 + 0], p0, acc[c], 0, 0, 0);
