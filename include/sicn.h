@@ -101,10 +101,13 @@ typedef struct sicn_options {
                              /*    128 -> 128), whatever the grid size; automatic: from 4 tiles per CU on              */
     int32_t prefetch;        /* 0: automatic; 1: never, 2 / 3: wherever it exists — the software-pipelined kernels      */
                              /*    (k_mfma16p.hip) for the shapes and grids the wide kernels do not take               */
-    int32_t persistent_grid; /* 0: one workgroup per CU (256); n: at most n (rounded down to a multiple of 8, >= 8)     */
+    int32_t persistent_grid; /* 0: one workgroup per CU; n: at most n (rounded down to a multiple of the XCD count)       */
                              /*    workgroups for the wide persistent kernels — tests use it to make every workgroup    */
                              /*    walk through many tiles of a small input                                            */
-    int32_t reserved[6];
+    int32_t split_k;         /* 0: automatic (grids that leave half of the CUs idle even after split_n); 1: never; > 1: always  */
+                             /*    where the form exists (the channel-split 8 x 16 kernels inside a net chain, whose workspace  */
+                             /*    holds the partial tensors) — K is split into channel-group pairs over workgroups, exact     */
+    int32_t reserved[5];
 } sicn_options;
 
 typedef struct sicn_weights sicn_weights; /* one layer's weights+bias, resident on the device  */
@@ -116,9 +119,20 @@ int sicn_has_alt_kernels(void);          /* 1: this build carries the alternate 
                                           * k_mfma.hip, `make ALT=1` -> libsicn_alt.so: parity tests only); 0: the product build,
                                           * which rejects sicn_options.mfma_shape = 32 with SICN_EINVAL */
 const char *sicn_strerror(int code);
+/* Device rule.  The library holds gfx950 code objects only: an entry point that would touch a device whose gcnArchName does not
+ * start with "gfx950" returns SICN_ENODEV (one line on stderr) — weights upload, layers, nets.  Grids, strip cuts and the
+ * XCD-aware tile order are sized from hipDeviceProp_t of the CURRENT device, read once per device: n_cu = multiProcessorCount,
+ * n_xcd = the largest power of two <= 8 that leaves at least 20 CUs per XCD (256 CUs -> 8, a DPX partition of 128 -> 4, QPX
+ * 64 -> 2, CPX 32 -> 1; hipDeviceProp_t carries no XCD count, and the value only steers which tiles share an L2).
+ * sicn_debug_plan shows what a layer would launch on a chip of n_cu CUs, without a GPU: out[] = { n_cu, n_xcd, kernel kind
+ * (0 generic, 1 mfma conv, 2 mfma deconv, 3 layer 0, 4 layer 7), mfma family (0 plain, 1 pipelined, 2 wide persistent), tile_x,
+ * split_n, split_k, grid x, grid y, grid z, strip chunks, layer-0 tiles per run }.  sicn_debug_xcd_item is the host mirror of
+ * the kernels' workgroup -> work item mapping (-1: padding workgroup). */
+int sicn_debug_plan(const sicn_layer_desc *desc, int n_images, const sicn_options *opt, int n_cu, int32_t out[12]);
+long long sicn_debug_xcd_item(long long block, long long n_items, int n_xcd);
 int sicn_validate_desc(const sicn_layer_desc *desc); /* pure host check, no GPU needed         */
 /* Fills *opt with the library defaults (= all zero, overridden by the SICN_MFMA_SHAPE, SICN_TILE_X,
- * SICN_STRIP_CHUNKS, SICN_NO_PHASE_LAYOUT, SICN_SPLIT_N, SICN_WAVE_TILE, SICN_PREFETCH, SICN_FORCE_GENERIC environment
+ * SICN_STRIP_CHUNKS, SICN_NO_PHASE_LAYOUT, SICN_SPLIT_N, SICN_SPLIT_K, SICN_WAVE_TILE, SICN_PREFETCH, SICN_FORCE_GENERIC environment
  * variables as they were when the library was loaded; out-of-range values are ignored with one warning on stderr). */
 void sicn_options_init(sicn_options *opt);
 
@@ -159,10 +173,16 @@ int sicn_net_create(const sicn_layer_desc *descs, sicn_weights *const *weights, 
 int sicn_net_create_opt(const sicn_layer_desc *descs, sicn_weights *const *weights, int n_layers,
                         const sicn_options *opt, sicn_net **out);
 void sicn_net_free(sicn_net *net);
-/* Bytes of DEVICE scratch `sicn_net_forward` needs for a batch of n_images. */
+/* Bytes of DEVICE scratch `sicn_net_forward` needs for a batch of n_images: two ping-pong activation buffers and, for chains
+ * whose grids are small enough for the K split (sicn_options.split_k), the slices' partial output tensors and one arrival word
+ * per workgroup.  The scratch needs NO initialisation: an arrival word only counts when it carries the net's random 56-bit tag,
+ * and the workgroup that finishes a tile clears it (any other content, e.g. uninitialised memory, reads as "nobody arrived").
+ * Depends on the current device's CU count (K split is a small-grid measure); asked without a device it assumes 256 CUs. */
 size_t sicn_net_workspace_bytes(const sicn_net *net, int n_images);
-/* Runs layers [first_layer, last_layer] of the chain.  `tap_layer` >= 0 additionally copies that
- * layer's output (e.g. 3 = the latent, conv_3_out, conv_nonsquare_top.cpp:322-325) to `tap_out`. */
+/* Runs layers [first_layer, last_layer] of the chain.  `tap_layer` >= 0 additionally delivers that
+ * layer's output (e.g. 3 = the latent, conv_3_out, conv_nonsquare_top.cpp:322-325) in `tap_out` (NHWC): an inner
+ * tapped layer is written straight into `tap_out` and the next layer reads it from there (no copy), so `tap_out`
+ * must not overlap `in`, `out` or the workspace and must stay untouched until the call has run. */
 int sicn_net_forward(const sicn_net *net, int first_layer, int last_layer, const uint8_t *in,
                      uint8_t *out, int tap_layer, uint8_t *tap_out, int n_images, void *workspace,
                      size_t workspace_bytes, void *hip_stream);

@@ -19,7 +19,7 @@ _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 class COptions(ctypes.Structure):
     """ctypes image of `sicn_options` (include/sicn.h): kernel-selection knobs, passed by value per call / per net."""
     _fields_ = [(n, ctypes.c_int32) for n in ("struct_bytes", "force_generic", "mfma_shape", "tile_x", "strip_chunks",
-                                              "no_phase_layout", "split_n", "wave_tile", "prefetch", "persistent_grid")] + [("reserved", ctypes.c_int32 * 6)]
+                                              "no_phase_layout", "split_n", "wave_tile", "prefetch", "persistent_grid", "split_k")] + [("reserved", ctypes.c_int32 * 5)]
 
 
 def make_options(**kw) -> "COptions":
@@ -56,6 +56,8 @@ ABI = {
     "sicn_eight_layers_net": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "sicn_net_profile": (_i, [_vp, _i]),
     "sicn_net_layer_ms": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]),
+    "sicn_debug_plan": (_i, [_descp, _i, ctypes.POINTER(COptions), _i, ctypes.POINTER(ctypes.c_int32)]),
+    "sicn_debug_xcd_item": (ctypes.c_longlong, [ctypes.c_longlong, ctypes.c_longlong, _i]),
 }
 
 

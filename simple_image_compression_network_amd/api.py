@@ -239,7 +239,7 @@ class EightLayersNet:
         else:
             _lib.check(L.sicn_net_create_opt(cdescs, handles, n, _opt_ptr(options), ctypes.byref(self._h)), "sicn_net_create_opt")
         self._ws = None
-        self._ws_images = 0
+        self._ws_bytes = {}
 
     def __del__(self):
         try:
@@ -251,10 +251,13 @@ class EightLayersNet:
 
     def workspace(self, n_images: int):
         import torch
-        if self._ws is None or self._ws_images < n_images:
-            nbytes = _lib.lib().sicn_net_workspace_bytes(self._h, n_images)
-            self._ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
-            self._ws_images = n_images
+        # sized per batch size (the K-split scratch of a small batch may exceed what a larger one asks for); never shrinks.
+        # No initialisation is needed (sicn.h: the arrival words carry the net's random tag).
+        nbytes = self._ws_bytes.get(n_images)
+        if nbytes is None:
+            nbytes = self._ws_bytes[n_images] = max(int(_lib.lib().sicn_net_workspace_bytes(self._h, n_images)), 256)
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._ws
 
     def forward(self, in_, out=None, latent=None, numReps: Optional[int] = None, want_latent: bool = True, stream=None):

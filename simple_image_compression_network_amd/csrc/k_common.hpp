@@ -1,6 +1,7 @@
 // Device-side helpers shared by the MFMA kernels (k_mfma.hip, k_rgb.hip).
 #pragma once
 #include "sicn_internal.h"
+#include "sicn_plan.h"
 
 namespace sicn {
 
@@ -167,14 +168,13 @@ __device__ __forceinline__ void load_piece(uint8_t *patch, const uint8_t *in_img
 // lines at their common edge) should run on the SAME XCD at about the same time: XCD x works through
 // the contiguous range [x * per, (x+1) * per) of the logical work list.  Returns the logical index of
 // this workgroup, or -1 if it has none (the grid is padded to a multiple of 8).
-constexpr int N_XCD = 8;
-__device__ __forceinline__ int xcd_logical_index(int n_items)
+// n_xcd is a kernel argument: the launcher takes it from the device (sicn_plan.h, chip_geom()); host and device only have to agree.
+__device__ __forceinline__ int xcd_logical_index(int n_items, int n_xcd)
 {
-    const int per = (n_items + N_XCD - 1) / N_XCD;
-    const int l = (int)blockIdx.x, idx = (l % N_XCD) * per + l / N_XCD;
-    return (l / N_XCD < per && idx < n_items) ? idx : -1;
+    const int per = (n_items + n_xcd - 1) / n_xcd;
+    const int l = (int)blockIdx.x, idx = (l % n_xcd) * per + l / n_xcd;
+    return (l / n_xcd < per && idx < n_items) ? idx : -1;
 }
-__host__ inline unsigned xcd_grid_size(int n_items) { return (unsigned)((n_items + N_XCD - 1) / N_XCD * N_XCD); }
 
 // ---- conv tap order: by parity plane (a,b) = (ky&1, kx&1), so that a plane's LDS buffer is
 // ---- free for the next channel group as soon as its taps are done (k_mfma.hip) -------------

@@ -232,7 +232,7 @@ template <int NQ, int NT16, bool DECONV, int MINW, int TX>
 __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
     const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int8_t *__restrict__ wstream,
     const int8_t *__restrict__ bias, int IW, int IH, int OW, int OH, int MW, int MH, int tiles_x, int n_tiles, int n_images,
-    int in_layout, int out_layout, uint32_t act_floor)
+    int in_layout, int out_layout, uint32_t act_floor, int n_xcd)
 {
     static_assert(NQ % 2 == 0, "channel groups are consumed in pairs");
     constexpr int CIN = NQ * 32, COUT = NT16 * 16;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, MINW) void k_mfma16_t(
     const int pos = lane & 15, g = lane >> 4, hi = g >> 1, half = g & 1;
     // logical work list: tile x (fastest), tile y, image; an XCD gets a contiguous range of it, so the
     // tiles that share halo pixels share an L2 (k_common.hpp)
-    const int item = xcd_logical_index(n_tiles * n_images);
+    const int item = xcd_logical_index(n_tiles * n_images, n_xcd);
     if (item < 0) return;   // before any LDS-DMA is issued
     const int img = item / n_tiles, tile = item - img * n_tiles;
     const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
@@ -355,7 +355,7 @@ constexpr int minw16(int NQ, int NT16, int TX) { return (TX == 16 || (NT16 <= 8 
 #define SICN_INST16(NQ, NT16, D, TX)                                                                             \
     template __global__ void k_mfma16_t<NQ, NT16, D, minw16(NQ, NT16, TX), TX>(                                    \
         const uint8_t *__restrict__, uint8_t *__restrict__, const int8_t *__restrict__, const int8_t *__restrict__, \
-        int, int, int, int, int, int, int, int, int, int, int, uint32_t);
+        int, int, int, int, int, int, int, int, int, int, int, uint32_t, int);
 SICN_INST16(4, 8, true, 32)
 SICN_INST16(6, 8, true, 32)
 SICN_INST16(4, 8, false, 32)
@@ -373,7 +373,7 @@ SICN_INST16(4, 12, true, 16)
 
 template <int NQ, int NT16, bool DECONV, int TX>
 static hipError_t launch16_tx(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
-                              hipStream_t stream, int in_layout, int out_layout, bool relu)
+                              hipStream_t stream, int in_layout, int out_layout, bool relu, const ChipGeom &chip)
 {
     constexpr int NSUB = DECONV ? NQ : 4;
     constexpr int MINW = minw16(NQ, NT16, TX);
@@ -383,58 +383,80 @@ static hipError_t launch16_tx(const LayerGeom &g, const sicn_weights &w, const u
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mfma16_t<NQ, NT16, DECONV, MINW, TX>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    dim3 grid(xcd_grid_size(tiles_x * tiles_y * n_images));
+    dim3 grid(xcd_grid_size((long)tiles_x * tiles_y * n_images, chip.n_xcd));
     hipLaunchKernelGGL((k_mfma16_t<NQ, NT16, DECONV, MINW, TX>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias,
                        g.IW, g.IH, g.OW, g.OH, MW, MH, tiles_x, tiles_x * tiles_y, n_images, in_layout, out_layout,
-                       (relu ? ACT_FLOOR_RELU : ACT_FLOOR_RAW) | (nt_store_wanted((size_t)g.OH * g.OW * g.COUT * n_images) ? ACT_NT_STORE : 0u));
+                       (relu ? ACT_FLOOR_RELU : ACT_FLOOR_RAW) | (nt_store_wanted((size_t)g.OH * g.OW * g.COUT * n_images) ? ACT_NT_STORE : 0u),
+                       chip.n_xcd);
     return hipGetLastError();
 }
 
-// Tile width: 8 x 32 positions by default; 8 x 16 where the wide tile allows only one workgroup per CU
-// (the 192-channel layers) or leaves most of the chip without a tile (small images).  sicn_options.tile_x = 16|32
-// forces one (experiments, tests).
-template <int NQ, int NT16, bool DECONV>
-static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
-                           hipStream_t stream, int in_layout, int out_layout, const sicn_options &o, bool relu)
+// Which kernel family, tile width and splits a conv / deconv layer runs with (pure: sicn_debug_plan walks it without a GPU).
+//   family 2: the wide persistent form (k_mfma16x.hip: one workgroup of 4 waves per CU, 16 x 32 positions, 128 x 128 outputs per
+//             wave) where every CU gets at least WIDE_MIN_TILES_PER_CU tiles; sicn_options.wave_tile = 128 forces it, 64 forbids it
+//   family 1: the software-pipelined 8 x 16 / 8 x 32 kernels (k_mfma16p.hip), the default wherever they exist
+//   family 0: the plain kernels of this file
+// Tile width: 8 x 32 positions by default; 8 x 16 where the wide tile allows only one workgroup per CU (the 192-channel layers)
+// or leaves most of the chip without a tile (small images).  sicn_options.tile_x = 16 | 32 forces one (experiments, tests).
+MfmaPlan plan_mfma(const LayerGeom &g, int n_images, const sicn_options &o, const ChipGeom &chip)
 {
-    const int MW = DECONV ? g.IW : g.OW, MH = DECONV ? g.IH : g.OH;
-    // the wide persistent form (k_mfma16x.hip: one workgroup of 4 waves per CU, 16 x 32 positions, 128 x 128 outputs per wave):
-    // where every CU gets at least WIDE_MIN_TILES tiles; sicn_options.wave_tile = 128 forces it, 64 forbids it
+    const bool deconv = g.transposed != 0;
+    const int nq = g.CIN / 32, nt16 = g.COUT / 16;
+    const int MW = deconv ? g.IW : g.OW, MH = deconv ? g.IH : g.OH;
+    MfmaPlan p{0, 32, 1, 1, 0, 1, 1};
     if (wide_supported(g) && o.tile_x != 16) {
         const long tiles_w = (long)((MW + 31) / 32) * ((MH + 15) / 16) * n_images;
-        // automatic: from WIDE_MIN_TILES tiles per CU on, the conv already from 3.5 rounds of 256 tiles when the last round is at
-        // least 90 % full (measured r03, tools/ab_options.py, 1080p x 4 and 4K x 1 = 1020 tiles: layer 1 131 - 140 against
-        // 144 - 149 us; at 255 / 510 tiles the wide conv loses, 44 / 39 and 70 / 68 us; the deconv is a wash below 1024: 45 / 47,
-        // 75 / 75, 146 / 142 us)
-        const long rounds = (tiles_w + 255) / 256;
-        const bool full_rounds = tiles_w * 10 >= rounds * 256 * 9;
-        const bool automatic = tiles_w >= 256L * WIDE_MIN_TILES || (!DECONV && full_rounds && 2 * tiles_w >= 7 * 256);
-        if (o.wave_tile == 128 || (o.wave_tile == 0 && o.prefetch == 0 && automatic))
-            return launch_wide(g, w, in, out, n_images, stream, in_layout, out_layout, relu, o.persistent_grid);
-    }
-    const long tiles32 = (long)((MW + 31) / 32) * ((MH + TILE_Y - 1) / TILE_Y) * n_images;
-    // 8 x 32 tiles from about 0.8 of one residency (2 workgroups x 256 CUs) on: below that the 8 x 16 tiles' second, partly filled
-    // round is still cheaper; measured r03 on one image of 1440 x 810 ... 1920 x 1080 (312 ... 506 tiles of 8 x 32), layer 1 / 6:
-    // 8 x 16 tiles 30 31 | 38 39 39 / 39 40 | 47 47 46 us, 8 x 32 tiles 35 35 | 35 36 36 / 40 40 | 41 42 41 us (the bar at 434 tiles)
-    bool narrow = minw16(NQ, NT16, 32) == 1 || tiles32 < 416;
-    if (o.tile_x == 16) narrow = true;
-    if (o.tile_x == 32) narrow = false;
-    // the software-pipelined form of the same kernels (k_mfma16p.hip) is the default wherever it exists
-    {
-        const int tx = narrow ? 16 : 32;
-        if (o.prefetch != 1 && pipelined_supported(g, tx)) {
-            // grids that leave half of the CUs without a workgroup: split the output channels over 2 / 3 workgroups
-            // (measured, r02: at 192 - 255 tiles the split is a wash or a loss; at <= 72 it takes 20 - 35 % off the layer)
-            const long tiles16 = (long)((MW + 15) / 16) * ((MH + TILE_Y - 1) / TILE_Y) * n_images;
-            const bool split = tx == 16 && (o.split_n > 1 || (o.split_n == 0 && tiles16 <= 128));
-            // (round 2 sent the deconv 192 -> 128 on full grids back to the plain kernel: the pipelined one was 7 % slower there.  The
-            // reason was the v_mov copies hipcc made for its run-time buffer parity — right around the asm MFMAs, where
-            // tools/isa_hazards.py found them; with the parity static the pipelined form is 17 % FASTER: layer 4 0.158 -> 0.131 ms.)
-                return launch_pipelined(g, w, in, out, n_images, stream, in_layout, out_layout, relu, tx, split);
+        // measured r03 (tools/ab_options.py, 1080p x 4 and 4K x 1 = 1020 tiles of 256 CUs): layer 1 131 - 140 against 144 - 149 us;
+        // at 255 / 510 tiles the wide conv loses, 44 / 39 and 70 / 68 us; the deconv is a wash below 1024: 45 / 47, 75 / 75, 146 / 142 us
+        if (o.wave_tile == 128 || (o.wave_tile == 0 && o.prefetch == 0 && wide_automatic(tiles_w, deconv, chip))) {
+            p.family = 2;
+            p.grid_x = wide_grid(tiles_w, o.persistent_grid, chip);
+            return p;
         }
     }
-    return narrow ? launch16_tx<NQ, NT16, DECONV, 16>(g, w, in, out, n_images, stream, in_layout, out_layout, relu)
-                  : launch16_tx<NQ, NT16, DECONV, 32>(g, w, in, out, n_images, stream, in_layout, out_layout, relu);
+    const long tiles32 = (long)((MW + 31) / 32) * ((MH + TILE_Y - 1) / TILE_Y) * n_images;
+    // 8 x 32 tiles from about 0.8 of one residency (2 workgroups per CU) on: below that the 8 x 16 tiles' second, partly filled
+    // round is still cheaper; measured r03 on one image of 1440 x 810 ... 1920 x 1080 (312 ... 506 tiles of 8 x 32), layer 1 / 6:
+    // 8 x 16 tiles 30 31 | 38 39 39 / 39 40 | 47 47 46 us, 8 x 32 tiles 35 35 | 35 36 36 / 40 40 | 41 42 41 us (the bar at 434 tiles)
+    bool narrow = minw16(nq, nt16, 32) == 1 || narrow_tile_wanted(tiles32, chip);
+    if (o.tile_x == 16) narrow = true;
+    if (o.tile_x == 32) narrow = false;
+    p.tile_x = narrow ? 16 : 32;
+    const long tiles = (long)((MW + p.tile_x - 1) / p.tile_x) * ((MH + TILE_Y - 1) / TILE_Y) * n_images;
+    p.grid_x = xcd_grid_size(tiles, chip.n_xcd);
+    if (o.prefetch != 1 && pipelined_supported(g, p.tile_x)) {
+        p.family = 1;
+        // grids that leave half of the CUs without a workgroup: split the output channels over 2 / 3 workgroups
+        // (measured, r02: at 192 - 255 tiles the split is a wash or a loss; at <= 72 it takes 20 - 35 % off the layer)
+        if (p.tile_x == 16 && (o.split_n > 1 || (o.split_n == 0 && split_n_automatic(tiles, chip)))) p.split_n = nt16 / 4;
+        // ... and the ones that are still small then: split K as well (round 4; only the channel-split 8 x 16 kernels have the form)
+        if (p.split_n > 1) {
+            const size_t out_bytes = (size_t)g.OH * g.OW * g.COUT * n_images;
+            int ks = o.split_k > 1 ? nq / 2 : (o.split_k == 0 ? split_k_automatic(tiles * p.split_n, nq, deconv, out_bytes, chip) : 1);
+            p.split_k = ks;
+        }
+        p.grid_y = p.split_n;
+        p.grid_z = p.split_k;
+    }
+    return p;
+}
+
+template <int NQ, int NT16, bool DECONV>
+static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
+                           hipStream_t stream, int in_layout, int out_layout, const sicn_options &o, const ChipGeom &chip, bool relu,
+                           const KSplitScratch *ks)
+{
+    MfmaPlan p = plan_mfma(g, n_images, o, chip);
+    if (p.family == 2) return launch_wide(g, w, in, out, n_images, stream, in_layout, out_layout, relu, o.persistent_grid, chip);
+    if (p.family == 1) {
+        // (round 2 sent the deconv 192 -> 128 on full grids back to the plain kernel: the pipelined one was 7 % slower there.  The
+        // reason was the v_mov copies hipcc made for its run-time buffer parity — right around the asm MFMAs, where
+        // tools/isa_hazards.py found them; with the parity static the pipelined form is 17 % FASTER: layer 4 0.158 -> 0.131 ms.)
+        if (p.split_k > 1 && !ksplit_scratch_fits(g, n_images, p, ks)) p.split_k = 1;   // no scratch (single-layer entry points): unsplit
+        return launch_pipelined(g, w, in, out, n_images, stream, in_layout, out_layout, relu, p.tile_x, p.split_n > 1, chip, p.split_k, ks);
+    }
+    return p.tile_x == 16 ? launch16_tx<NQ, NT16, DECONV, 16>(g, w, in, out, n_images, stream, in_layout, out_layout, relu, chip)
+                          : launch16_tx<NQ, NT16, DECONV, 32>(g, w, in, out, n_images, stream, in_layout, out_layout, relu, chip);
 }
 
 // shapes the 16x16x64 kernels serve: the reference net's L1-L6 plus the hyperprior stacks' conv 192 -> 128 and deconv 128 -> 192
@@ -445,18 +467,19 @@ bool mfma_supported(int cin, int cout, int transposed)
 }
 
 hipError_t launch_mfma16(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
-                         hipStream_t stream, int in_layout, int out_layout, const sicn_options &o, bool relu)
+                         hipStream_t stream, int in_layout, int out_layout, const sicn_options &o, const ChipGeom &chip, bool relu,
+                         const KSplitScratch *ks)
 {
     if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB) return hipErrorInvalidValue;          // 31-bit patch offsets
     if ((size_t)g.OH * g.OW * g.COUT >= (size_t)OOB) return hipErrorInvalidValue;         // buffer-descriptor stores
     if (g.transposed) {
-        if (g.CIN == 128 && g.COUT == 128) return launch16<4, 8, true>(g, w, in, out, n_images, stream, in_layout, out_layout, o, relu);
-        if (g.CIN == 192 && g.COUT == 128) return launch16<6, 8, true>(g, w, in, out, n_images, stream, in_layout, out_layout, o, relu);
-        if (g.CIN == 128 && g.COUT == 192) return launch16<4, 12, true>(g, w, in, out, n_images, stream, in_layout, out_layout, o, relu);
+        if (g.CIN == 128 && g.COUT == 128) return launch16<4, 8, true>(g, w, in, out, n_images, stream, in_layout, out_layout, o, chip, relu, ks);
+        if (g.CIN == 192 && g.COUT == 128) return launch16<6, 8, true>(g, w, in, out, n_images, stream, in_layout, out_layout, o, chip, relu, ks);
+        if (g.CIN == 128 && g.COUT == 192) return launch16<4, 12, true>(g, w, in, out, n_images, stream, in_layout, out_layout, o, chip, relu, ks);
     } else {
-        if (g.CIN == 192 && g.COUT == 128) return launch16<6, 8, false>(g, w, in, out, n_images, stream, in_layout, out_layout, o, relu);
-        if (g.CIN == 128 && g.COUT == 128) return launch16<4, 8, false>(g, w, in, out, n_images, stream, in_layout, out_layout, o, relu);
-        if (g.CIN == 128 && g.COUT == 192) return launch16<4, 12, false>(g, w, in, out, n_images, stream, in_layout, out_layout, o, relu);
+        if (g.CIN == 192 && g.COUT == 128) return launch16<6, 8, false>(g, w, in, out, n_images, stream, in_layout, out_layout, o, chip, relu, ks);
+        if (g.CIN == 128 && g.COUT == 128) return launch16<4, 8, false>(g, w, in, out, n_images, stream, in_layout, out_layout, o, chip, relu, ks);
+        if (g.CIN == 128 && g.COUT == 192) return launch16<4, 12, false>(g, w, in, out, n_images, stream, in_layout, out_layout, o, chip, relu, ks);
     }
     return hipErrorInvalidValue;
 }
@@ -464,7 +487,7 @@ hipError_t launch_mfma16(const LayerGeom &g, const sicn_weights &w, const uint8_
 // ---- host-side weight packing: the same tile sequence as pack_mfma_stream, rows in the 16x16 C/D
 // ---- order (LDS row j*16 + rho holds channel 64*(j>>2) + 16*(rho>>2) + 4*(j&3) + (rho&3)), no swizzle
 // zero tiles behind the stream: the deepest prefetch of any kernel that walks it (k_mfma16: PF16 = 6, k_mfma16w: 8, k_mfma16p: 12)
-constexpr int PAD16 = 12;
+constexpr int PAD16 = 24;
 static_assert(PAD16 >= PF16, "prefetch would run off the stream");
 size_t mfma16_stream_bytes(int cin, int cout) { return (size_t)(25 * (cin / 32) + PAD16) * cout * KSTEP; }
 

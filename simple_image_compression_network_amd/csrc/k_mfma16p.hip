@@ -42,7 +42,7 @@ struct Ring {
 #define SICN_MFMA_V(ACC, A, B) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
 #define SICN_MFMA_V_C(ACC, A, B, C) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %3" : "=&v"(ACC) : "v"(A), "v"(B), "v"(C))
 
-constexpr int PAD_TILES_P = 12;   // zero tiles behind a weight stream (k_mfma16.hip: PAD16)
+constexpr int PAD_TILES_P = 24;   // zero tiles behind a weight stream (k_mfma16.hip: PAD16)
 template <int NT16>
 struct WTile {
     static constexpr int TB = NT16 * 16 * KSTEP;     // 4096 / 6144 bytes
@@ -53,10 +53,12 @@ struct WTile {
 // NTF = weight tiles (of 16 channels) of the whole layer: the stride of the stream; NT16 <= NTF = the ones this workgroup
 // computes (output-channel split, see launch_p); `wstream` already points at its first row
 template <int NT16, int NTF, int PF>
-__device__ __forceinline__ void load_wtile_p(uint8_t *ring, const int8_t *wstream, int tile, int lane, int w)
+__device__ __forceinline__ void load_wtile_p(uint8_t *ring, const int8_t *wstream, int tile, int lane, int w, int src_tile = -1)
 {
+    // `tile`: the running number of the K step in THIS workgroup's walk (ring slot = tile % PF); src_tile: where it sits in the
+    // layer's stream when the two differ (K split of a deconv: a slice walks every (NQ / NQL)-th group pair), -1 = the same
     constexpr int TB = WTile<NT16>::TB, NPB = WTile<NT16>::NPB, WR = WTile<NT16>::WR;
-    const int8_t *src = wstream + (size_t)tile * WTile<NTF>::TB + lane * 16;
+    const int8_t *src = wstream + (size_t)(src_tile < 0 ? tile : src_tile) * WTile<NTF>::TB + lane * 16;
     uint8_t *dst = ring + (tile % PF) * TB;
 #pragma unroll
     for (int r = 0; r < WR; r++) {
@@ -206,30 +208,125 @@ __device__ __forceinline__ void store_tiles_p(v4i (&acc)[Geo<TX>::NC][NT16], uin
     }
 }
 
+// ---- K split (round 4): the channel-group pairs of a layer over KS workgroups (blockIdx.z) -----------------------------------
+// Small grids leave most CUs idle while every workgroup walks a serial chain of 50 - 75 passes.  The M tiles cannot multiply and the
+// output channels are already split (launch_p), so K is: slice z computes the partial sums of channel groups [z NQ / KS, (z + 1) NQ / KS)
+// — slice 0 starts from the bias, the others from 0 — and stores their LOW BYTES (Z -> Z/256 is a ring homomorphism: the truncation
+// may come before the final sum, conv_nonsquare_top.cpp:272 / mvau.hpp:160-170 only define the result mod 256) as a partial
+// tensor of the layer's output shape in the caller's workspace.  Who finishes a tile is decided by ONE 64-bit word per (tile,
+// channel slice): upper 56 bits = the net's random tag, low bits = arrival mask, updated by compare-and-swap (a single location,
+// so the updates are totally ordered).  Whoever completes the mask adds the KS partial tensors byte-wise mod 256, applies the
+// activation, stores the tile and clears the word.  A word that does not carry the tag (uninitialised workspace) counts as
+// empty: no initialisation pass, no counter that must start at zero.
+struct KSplitArgs {
+    uint8_t *partials;            // [KS][n_images * out_img_bytes]
+    unsigned long long stride;    // bytes between two slices' tensors
+    unsigned long long *flags;    // [tiles * n_images][gridDim.y]
+    unsigned long long tag;       // random, low 8 bits zero, never 0
+};
+
+template <int KS>
+__device__ __forceinline__ bool ksplit_arrive(unsigned long long *word, unsigned long long tag, int z, uint8_t *lds_word)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // this thread's partial stores are visible device-wide ...
+    __syncthreads();                                     // ... and so are everybody else's of this workgroup
+    if (threadIdx.x == 0) {
+        unsigned long long cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want;
+        do {
+            const unsigned long long mask = ((cur ^ tag) >> 8) == 0 ? (cur & 0xffull) : 0ull;   // foreign content = nobody has arrived
+            want = tag | mask | (1ull << z);
+        } while (!__hip_atomic_compare_exchange_strong(word, &cur, want, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+        *(volatile uint32_t *)lds_word = (want & 0xffull) == ((1ull << KS) - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool last = *(volatile uint32_t *)lds_word != 0;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other slices' partial stores are visible to this workgroup
+    return last;
+}
+
+__device__ __forceinline__ uint32_t add_bytes(uint32_t a, uint32_t b)   // four independent byte sums mod 256
+{
+    return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
+}
+__device__ __forceinline__ uint32_t relu7_bytes(uint32_t x)   // bytes >= 128 (negative as int8) -> 0
+{
+    const uint32_t m = (x >> 7) & 0x01010101u;
+    return x & ~((m << 8) - m);
+}
+
+// the finishing pass of a tile: the same pieces (16 bytes per lane) a normal epilogue stores, read from the KS partial tensors
+template <int TX, int NT16, int KS>
+__device__ __forceinline__ void ksplit_finish_tile(const uint8_t *part_img, unsigned long long stride, uint8_t *out_img, int out_img_bytes,
+                                                   const TensorMap &om, int MW, int MH, int Y0, int X0, int w, int pos, int g, bool deconv,
+                                                   uint32_t act_floor, uint32_t cg0)
+{
+    constexpr int NC = Geo<TX>::NC, XT = Geo<TX>::XT;
+    __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)out_img, 0, out_img_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rp[KS];
+#pragma unroll
+    for (int z = 0; z < KS; z++) rp[z] = __builtin_amdgcn_make_buffer_rsrc((void *)(part_img + (size_t)z * stride), 0, out_img_bytes, 0x00020000);
+    const bool relu = (act_floor & ACT_FLOOR_MASK) == ACT_FLOOR_RELU;
+    const int nph = deconv ? 4 : 1;
+    for (int ph = 0; ph < nph; ph++) {
+        const int py = ph >> 1, px = ph & 1;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int gy = Y0 + 2 * w + c / XT, gx = X0 + (c % XT) * 16 + pos;
+            const bool ok = gy < MH && gx < MW;
+            const int oy_ = deconv ? 2 * gy + py : gy, ox_ = deconv ? 2 * gx + px : gx;
+            const uint32_t off0 = tensor_offset(om, oy_, ox_, (uint32_t)(g >> 1) + cg0) + 16u * (g & 1);
+#pragma unroll
+            for (int J = 0; J < NT16 / 4; J++) {
+                const uint32_t off = ok ? off0 + (uint32_t)(2 * J) * om.grp : OOB;
+                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                v4u sum = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(rp[0], off, 0, 0));
+#pragma unroll
+                for (int z = 1; z < KS; z++) {
+                    const v4u v = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(rp[z], off, 0, 0));
+#pragma unroll
+                    for (int d = 0; d < 4; d++) sum[d] = add_bytes(sum[d], v[d]);
+                }
+                if (relu) {
+#pragma unroll
+                    for (int d = 0; d < 4; d++) sum[d] = relu7_bytes(sum[d]);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(sum, ro, off, 0, 0);
+            }
+        }
+    }
+}
+
 struct TileCoord {
     int img, Y0, X0;
     bool valid;
+    int item;   // logical index in the (tile x, tile y, image) list
 };
 template <int TX>
-__device__ __forceinline__ TileCoord tile_coord(int tiles_x, int n_tiles, int n_images)
+__device__ __forceinline__ TileCoord tile_coord(int tiles_x, int n_tiles, int n_images, int n_xcd)
 {
-    const int item = xcd_logical_index(n_tiles * n_images);
-    if (item < 0) return TileCoord{0, 0, 0, false};
+    const int item = xcd_logical_index(n_tiles * n_images, n_xcd);
+    if (item < 0) return TileCoord{0, 0, 0, false, 0};
     const int img = item / n_tiles, tile = item - img * n_tiles;
     const int tile_y = tile / tiles_x, tile_x = tile - tile_y * tiles_x;
-    return TileCoord{img, tile_y * TILE_Y, tile_x * TX, true};
+    return TileCoord{img, tile_y * TILE_Y, tile_x * TX, true, item};
 }
 
 // =====================================================================================================================
 // deconv522<>: NQ / 2 passes per tap (channel pairs q, q+1 of one tap), the tap loop stays a loop
 // =====================================================================================================================
-template <int NQ, int NT16, int NTF, int TX, int PF>
+template <int NQ, int NT16, int NTF, int TX, int PF, int KS>
 __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                      const int8_t *__restrict__ wstream, const int8_t *__restrict__ bias, int IW, int IH,
                                                      int OW, int OH, int tiles_x, int n_tiles, int n_images, int in_layout,
-                                                     int out_layout, uint32_t act_floor)
+                                                     int out_layout, uint32_t act_floor, int n_xcd, KSplitArgs ks)
 {
-    constexpr int CIN = NQ * 32, COUT = NTF * 16, COUTW = NT16 * 16, NC = Geo<TX>::NC, PPT = NQ / 2;   // passes per tap
+    // KS > 1: K split — this workgroup (blockIdx.z) walks NQL = NQ / KS = 2 of the layer's NQ channel groups (one pass per tap)
+    constexpr int NQL = NQ / KS;
+    static_assert(NQ % KS == 0 && (KS == 1 || NQL == 2), "a K slice is one channel-group pair");
+    constexpr int CIN = NQ * 32, COUT = NTF * 16, COUTW = NT16 * 16, NC = Geo<TX>::NC, PPT = NQL / 2;   // passes per tap
+    const int zs = KS > 1 ? (int)blockIdx.z : 0;
+    // position of the workgroup's K step `L` (tap-major, its own groups) in the layer's stream (tap-major, all NQ groups)
+    auto src_tile = [&](int L) { return KS == 1 ? -1 : (L / NQL) * NQ + zs * NQL + L % NQL; };
     constexpr int PX = Geo<TX>::PX, ALLOC = Geo<TX>::ALLOC, SLOTS = Geo<TX>::SLOTS;
     constexpr int TB = WTile<NT16>::TB, WR = WTile<NT16>::WR;
     const int split = blockIdx.y;                    // this workgroup's COUTW output channels start at split * COUTW
@@ -241,12 +338,12 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
     constexpr int BIAS_LDS = (Geo<TX>::PIX * KSTEP + 1023) / 1024 * 1024;   // the padding pieces behind sub-patch 0's positions
     static_assert(BIAS_LDS + COUTW <= ALLOC, "no room for the bias behind the patch");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *patch = smem, *ring = smem + NQ * ALLOC;
+    uint8_t *patch = smem, *ring = smem + NQL * ALLOC;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pos = lane & 15, g = lane >> 4, hi = g >> 1, half = g & 1;
-    const TileCoord tc = tile_coord<TX>(tiles_x, n_tiles, n_images);
+    const TileCoord tc = tile_coord<TX>(tiles_x, n_tiles, n_images, n_xcd);
     if (!tc.valid) return;   // before any LDS-DMA is issued
 #ifdef SICN_STAMP
     unsigned long long dst[10];   // start, loop start, then (passes done, epilogue done) per phase
@@ -267,15 +364,15 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
     for (int slot = 0; slot < SLOTS; slot++) {
         const PieceSrc ps = piece_src<TX>(im, slot * 4 + w, lane, Y0 - 1, X0 - 1, 1, 0, 0, IW, IH);
 #pragma unroll
-        for (int sub = 0; sub < NQ; sub++)
-            load_piece<ALLOC>(patch, in_img, in_img_bytes, sub, slot * 4 + w, ps.ok ? ps.off + (uint32_t)sub * im.grp : OOB);
+        for (int sub = 0; sub < NQL; sub++)
+            load_piece<ALLOC>(patch, in_img, in_img_bytes, sub, slot * 4 + w, ps.ok ? ps.off + (uint32_t)(zs * NQL + sub) * im.grp : OOB);
     }
 #pragma unroll
-    for (int s = 0; s < PF; s++) load_wtile_p<NT16, NTF, PF>(ring, wstream, s, lane, w);
+    for (int s = 0; s < PF; s++) load_wtile_p<NT16, NTF, PF>(ring, wstream, s, lane, w, src_tile(s));
     // the bias goes to LDS (padding behind sub-patch 0): reading it from global memory at the start of every phase would make
-    // hipcc drain vmcnt there, i.e. wait for the previous phase's stores
+    // hipcc drain vmcnt there, i.e. wait for the previous phase's stores.  (K split: only slice 0 starts from the bias.)
     uint32_t bias_dw = 0;
-    if (tid < COUTW / 4) bias_dw = ((const uint32_t *)bias)[tid];
+    if (tid < COUTW / 4 && zs == 0) bias_dw = ((const uint32_t *)bias)[tid];
     wait_vmcnt<0>();
     block_barrier();   // every wave's DMA has landed — including the padding piece (zeros) the bias is about to replace
     if (tid < COUTW / 4) ((uint32_t *)(patch + BIAS_LDS))[tid] = bias_dw;
@@ -306,8 +403,8 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
             const uint8_t *pixn = lane_pix + (last ? toff_next : toff + (uint32_t)((q + 2) * ALLOC));
             const uint8_t *wtn = lane_wt + (uint32_t)(((s0 + 2 + hi) % PF) * TB);
             auto dma = [&]() {
-                load_wtile_p<NT16, NTF, PF>(ring, wstream, s0 + PF, lane, w);
-                load_wtile_p<NT16, NTF, PF>(ring, wstream, s0 + 1 + PF, lane, w);
+                load_wtile_p<NT16, NTF, PF>(ring, wstream, s0 + PF, lane, w, src_tile(s0 + PF));
+                load_wtile_p<NT16, NTF, PF>(ring, wstream, s0 + 1 + PF, lane, w, src_tile(s0 + 1 + PF));
             };
             // the previous phase's NSTORE stores are younger than the tiles awaited in the first FL passes of a phase: they
             // are counted, not waited for
@@ -326,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
                 pass_p<TX, NT16, VM, NSTORE, false, NWB == 2>(acc, wc, wn, pc, pn, pixn, wtn, extra, none, dma);
             }
         }
-        step += NQ;
+        step += NQL;
     };
 #ifdef SICN_STAMP
     dst[1] = __builtin_amdgcn_s_memtime();
@@ -381,11 +478,23 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
         dst[2 + 2 * ph] = __builtin_amdgcn_s_memtime();
 #endif
         if (ph == 3) wait_vmcnt<0>();  // the padded tail of the weight prefetch must land before exit
-        store_tiles_p<TX, NT16>(acc, out_img, out_img_bytes, om, IW, IH, Y0, X0, w, pos, g, true, py, px, act_floor,
-                                (uint32_t)(split * (COUTW / 32)));
+        if constexpr (KS == 1)
+            store_tiles_p<TX, NT16>(acc, out_img, out_img_bytes, om, IW, IH, Y0, X0, w, pos, g, true, py, px, act_floor,
+                                    (uint32_t)(split * (COUTW / 32)));
+        else   // this slice's partial sums, low bytes, no activation, into its own tensor of the output's shape
+            store_tiles_p<TX, NT16>(acc, ks.partials + (size_t)zs * ks.stride + (size_t)tc.img * out_img_bytes, out_img_bytes, om, IW, IH, Y0,
+                                    X0, w, pos, g, true, py, px, ACT_FLOOR_RAW, (uint32_t)(split * (COUTW / 32)));
 #ifdef SICN_STAMP
         dst[3 + 2 * ph] = __builtin_amdgcn_s_memtime();
 #endif
+    }
+    if constexpr (KS > 1) {
+        unsigned long long *word = ks.flags + (size_t)tc.item * gridDim.y + blockIdx.y;
+        if (ksplit_arrive<KS>(word, ks.tag, zs, smem)) {
+            ksplit_finish_tile<TX, NT16, KS>(ks.partials + (size_t)tc.img * out_img_bytes, ks.stride, out_img, out_img_bytes, om, IW, IH, Y0, X0,
+                                             w, pos, g, true, act_floor, (uint32_t)(split * (COUTW / 32)));
+            if (tid == 0) __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // empty again for the next launch
+        }
     }
 #ifdef SICN_STAMP
     if (g_sicn_stamp && lane == 0) {
@@ -479,24 +588,28 @@ __device__ __forceinline__ void conv_passes_p(v4i (&acc)[Geo<TX>::NC][NT16], v4i
     if constexpr (P + 1 < NPASS) conv_passes_p<TX, NT16, NTF, PF, P + 1, NPASS>(acc, wbuf, pa, pb, c, poff);
 }
 
-template <int NQ, int NT16, int NTF, int TX, int PF>
+template <int NQ, int NT16, int NTF, int TX, int PF, int KS>
 __global__ __launch_bounds__(256, 2) void k_conv_p(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                    const int8_t *__restrict__ wstream, const int8_t *__restrict__ bias, int IW, int IH,
                                                    int OW, int OH, int tiles_x, int n_tiles, int n_images, int in_layout, int out_layout,
-                                                   uint32_t act_floor)
+                                                   uint32_t act_floor, int n_xcd, KSplitArgs ks)
 {
-    constexpr int CIN = NQ * 32, COUT = NTF * 16, COUTW = NT16 * 16, NC = Geo<TX>::NC, NPASS = 25 * NQ / 2;
-    static_assert(NQ % 2 == 0, "channel groups are consumed in pairs");
+    // KS > 1: K split — this workgroup (blockIdx.z) walks channel groups [zs NQL, (zs + 1) NQL) only: one 25-pass window
+    constexpr int NQL = NQ / KS;
+    static_assert(NQ % KS == 0 && (KS == 1 || NQL == 2), "a K slice is one channel-group pair");
+    constexpr int CIN = NQ * 32, COUT = NTF * 16, COUTW = NT16 * 16, NC = Geo<TX>::NC, NPASS = 25 * NQL / 2;
+    static_assert(NQL % 2 == 0, "channel groups are consumed in pairs");
     constexpr int PX = Geo<TX>::PX, ALLOC = Geo<TX>::ALLOC, SLOTS = Geo<TX>::SLOTS, TB = WTile<NT16>::TB;
     const int split = blockIdx.y;                    // this workgroup's COUTW output channels start at split * COUTW
-    wstream += split * TB;
+    const int zs = KS > 1 ? (int)blockIdx.z : 0;
+    wstream += split * TB + (size_t)(zs * NQL * 25) * WTile<NTF>::TB;   // the stream is group-major: a slice's tiles are contiguous
     bias += split * COUTW;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *patch = smem, *ring = smem + 4 * ALLOC;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pos = lane & 15, g = lane >> 4, hi = g >> 1, half = g & 1;
-    const TileCoord tc = tile_coord<TX>(tiles_x, n_tiles, n_images);
+    const TileCoord tc = tile_coord<TX>(tiles_x, n_tiles, n_images, n_xcd);
     if (!tc.valid) return;
     const int Y0 = tc.Y0, X0 = tc.X0;
     const int in_img_bytes = IH * IW * CIN, out_img_bytes = OH * OW * COUT;
@@ -504,13 +617,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_p(const uint8_t *__restrict__ i
     uint8_t *out_img = out + (size_t)tc.img * out_img_bytes;
     const TensorMap im = tensor_map(in_layout, CIN, IW, IH), om = tensor_map(out_layout, COUT, OW, OH);
 
-    uint32_t poff[4][SLOTS];
+    uint32_t poff[4][SLOTS];   // channel group zs * NQL (the slice's first); out-of-image pieces stay beyond any image after the adds
 #pragma unroll
     for (int pl = 0; pl < 4; pl++)
 #pragma unroll
         for (int slot = 0; slot < SLOTS; slot++) {
             const PieceSrc ps = piece_src<TX>(im, slot * 4 + w, lane, Y0 - 1, X0 - 1, 2, pl >> 1, pl & 1, IW, IH);
-            poff[pl][slot] = ps.ok ? ps.off : OOB;
+            poff[pl][slot] = ps.ok ? ps.off + (uint32_t)(zs * NQL) * im.grp : OOB;
         }
 #ifdef SICN_STAMP
     unsigned long long st[3] = {0, 0, 0};
@@ -536,7 +649,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_p(const uint8_t *__restrict__ i
     v4i acc[NC][NT16];
 #pragma unroll
     for (int J = 0; J < NT16 / 4; J++) {
-        const v4i b4 = *(const v4i *)(bias + 64 * J + 16 * g);
+        v4i b4 = *(const v4i *)(bias + 64 * J + 16 * g);
+        if (KS > 1 && zs != 0) b4 = v4i{0, 0, 0, 0};   // K split: only slice 0 starts from the bias
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
             v4i v;
@@ -572,8 +686,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_p(const uint8_t *__restrict__ i
     const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime(), r_loop_end = __builtin_amdgcn_s_memrealtime();
 #endif
     wait_vmcnt<0>();
-    store_tiles_p<TX, NT16>(acc, out_img, out_img_bytes, om, OW, OH, Y0, X0, w, pos, g, false, 0, 0, act_floor,
-                            (uint32_t)(split * (COUTW / 32)));
+    if constexpr (KS == 1) {
+        store_tiles_p<TX, NT16>(acc, out_img, out_img_bytes, om, OW, OH, Y0, X0, w, pos, g, false, 0, 0, act_floor,
+                                (uint32_t)(split * (COUTW / 32)));
+    } else {
+        // this slice's partial sums, low bytes, no activation, into its own tensor of the output's shape; the last slice to arrive
+        // adds the KS tensors mod 256 and finishes the tile
+        store_tiles_p<TX, NT16>(acc, ks.partials + (size_t)zs * ks.stride + (size_t)tc.img * out_img_bytes, out_img_bytes, om, OW, OH, Y0, X0,
+                                w, pos, g, false, 0, 0, ACT_FLOOR_RAW, (uint32_t)(split * (COUTW / 32)));
+        unsigned long long *word = ks.flags + (size_t)tc.item * gridDim.y + blockIdx.y;
+        if (ksplit_arrive<KS>(word, ks.tag, zs, smem)) {
+            ksplit_finish_tile<TX, NT16, KS>(ks.partials + (size_t)tc.img * out_img_bytes, ks.stride, out_img, out_img_bytes, om, OW, OH, Y0, X0,
+                                             w, pos, g, false, act_floor, (uint32_t)(split * (COUTW / 32)));
+            if (tid == 0) __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // empty again for the next launch
+        }
+    }
 #ifdef SICN_STAMP
     if (g_sicn_stamp && lane == 0) {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
@@ -600,15 +727,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_p(const uint8_t *__restrict__ i
 // NT16 < NTF: output-channel split — blockIdx.y = which NT16 * 16 channels a workgroup computes.  Used on grids smaller
 // than the chip (fewer than two workgroups per CU): the tile count cannot grow, the channel dimension can; each workgroup
 // then runs the same number of passes with NT16 / NTF of the MFMAs, and the CUs that had no tile get one.
-template <int NQ, int NT16, int NTF, bool DECONV, int TX>
+template <int NQ, int NT16, int NTF, bool DECONV, int TX, int KS = 1>
 static hipError_t launch_p(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images, hipStream_t stream,
-                           int in_layout, int out_layout, bool relu)
+                           int in_layout, int out_layout, bool relu, const ChipGeom &chip, const KSplitScratch *ks = nullptr)
 {
-    constexpr int NSUB = DECONV ? NQ : 4;
+    constexpr int NSUB = DECONV ? NQ / KS : 4;
     // PF = 12 (4 passes of flight time) fits the 8 x 16 tiles of the 128-channel shapes but measured no gain on small grids
-    // (1080p: layer 6 51 vs 48 us): the weight stream's latency is not what bounds a pass there
+    // (1080p: layer 6 51 vs 48 us; round 4, the channel-split kernels at 256^2 ... 1080p with 12 / 16 / 24 slots: no gain either):
+    // the weight stream's latency is not what bounds a pass there
     constexpr int PF = 8;
     static_assert(PF <= PAD_TILES_P, "prefetch would run off the weight stream");
+    // K split of a deconv: a slice's prefetch runs up to tap 25 + PF / 2 of the tap-major stream
+    static_assert(KS == 1 || !DECONV || ((49 + PF) / 2 + 1) * NQ - 1 < 25 * NQ + PAD_TILES_P, "K-split prefetch would run off the weight stream");
     const int MW = DECONV ? g.IW : g.OW, MH = DECONV ? g.IH : g.OH;
     const int tiles_x = (MW + TX - 1) / TX, tiles_y = (MH + TILE_Y - 1) / TILE_Y;
     constexpr size_t lds_need = (size_t)NSUB * Geo<TX>::ALLOC + (size_t)PF * WTile<NT16>::TB;
@@ -621,19 +751,26 @@ static hipError_t launch_p(const LayerGeom &g, const sicn_weights &w, const uint
 #endif
     const uint32_t flags = (relu ? ACT_FLOOR_RELU : ACT_FLOOR_RAW) |
                            (nt_store_wanted((size_t)g.OH * g.OW * g.COUT * n_images) ? ACT_NT_STORE : 0u);
-    const dim3 grid(xcd_grid_size(tiles_x * tiles_y * n_images), NTF / NT16);
+    const dim3 grid(xcd_grid_size((long)tiles_x * tiles_y * n_images, chip.n_xcd), NTF / NT16, KS);
+    KSplitArgs ka{nullptr, 0, nullptr, 0};
+    if constexpr (KS > 1) {
+        if (!ks || !ks->partials || !ks->flags || ks->partial_stride < (size_t)g.OH * g.OW * g.COUT * (size_t)n_images ||
+            ks->n_flags < (size_t)grid.x * grid.y)
+            return hipErrorInvalidValue;
+        ka = KSplitArgs{ks->partials, (unsigned long long)ks->partial_stride, ks->flags, ks->nonce};
+    }
     if constexpr (DECONV) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_deconv_p<NQ, NT16, NTF, TX, PF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_deconv_p<NQ, NT16, NTF, TX, PF, KS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_deconv_p<NQ, NT16, NTF, TX, PF>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias, g.IW, g.IH, g.OW,
-                           g.OH, tiles_x, tiles_x * tiles_y, n_images, in_layout, out_layout, flags);
+        hipLaunchKernelGGL((k_deconv_p<NQ, NT16, NTF, TX, PF, KS>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias, g.IW, g.IH, g.OW,
+                           g.OH, tiles_x, tiles_x * tiles_y, n_images, in_layout, out_layout, flags, chip.n_xcd, ka);
     } else {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_p<NQ, NT16, NTF, TX, PF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_p<NQ, NT16, NTF, TX, PF, KS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_conv_p<NQ, NT16, NTF, TX, PF>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias, g.IW, g.IH, g.OW,
-                           g.OH, tiles_x, tiles_x * tiles_y, n_images, in_layout, out_layout, flags);
+        hipLaunchKernelGGL((k_conv_p<NQ, NT16, NTF, TX, PF, KS>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias, g.IW, g.IH, g.OW,
+                           g.OH, tiles_x, tiles_x * tiles_y, n_images, in_layout, out_layout, flags, chip.n_xcd, ka);
     }
     return hipGetLastError();
 }
@@ -647,11 +784,25 @@ bool pipelined_supported(const LayerGeom &g, int tx)
 }
 
 hipError_t launch_pipelined(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images, hipStream_t stream,
-                            int in_layout, int out_layout, bool relu, int tx, bool split)
+                            int in_layout, int out_layout, bool relu, int tx, bool split, const ChipGeom &chip, int split_k,
+                            const KSplitScratch *ks)
 {
     if (!pipelined_supported(g, tx)) return hipErrorInvalidValue;
     if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB || (size_t)g.OH * g.OW * g.COUT >= (size_t)OOB) return hipErrorInvalidValue;
-#define SICN_P(NQ, NT, NTF, D, TX) return launch_p<NQ, NT, NTF, D, TX>(g, w, in, out, n_images, stream, in_layout, out_layout, relu)
+#define SICN_P(NQ, NT, NTF, D, TX) return launch_p<NQ, NT, NTF, D, TX>(g, w, in, out, n_images, stream, in_layout, out_layout, relu, chip)
+#define SICN_PK(NQ, NT, NTF, D, TX) return launch_p<NQ, NT, NTF, D, TX, NQ / 2>(g, w, in, out, n_images, stream, in_layout, out_layout, relu, chip, ks)
+    if (split && tx == 16 && split_k > 1) {   // 64 output channels and one channel-group pair per workgroup (K split, round 4)
+        if (split_k != g.CIN / 64) return hipErrorInvalidValue;
+        if (g.transposed) {
+            if (g.CIN == 128 && g.COUT == 128) SICN_PK(4, 4, 8, true, 16);
+            if (g.CIN == 192 && g.COUT == 128) SICN_PK(6, 4, 8, true, 16);
+            if (g.CIN == 128 && g.COUT == 192) SICN_PK(4, 4, 12, true, 16);
+        } else {
+            if (g.CIN == 128 && g.COUT == 128) SICN_PK(4, 4, 8, false, 16);
+            if (g.CIN == 128 && g.COUT == 192) SICN_PK(4, 4, 12, false, 16);
+            if (g.CIN == 192 && g.COUT == 128) SICN_PK(6, 4, 8, false, 16);
+        }
+    }
     if (split && tx == 16) {   // 64 output channels per workgroup
         if (g.transposed) {
             if (g.CIN == 128 && g.COUT == 128) SICN_P(4, 4, 8, true, 16);
@@ -679,6 +830,7 @@ hipError_t launch_pipelined(const LayerGeom &g, const sicn_weights &w, const uin
         if (g.CIN == 192 && g.COUT == 128) SICN_P(6, 8, 8, false, 16);
     }
 #undef SICN_P
+#undef SICN_PK
     return hipErrorInvalidValue;
 }
 

@@ -242,9 +242,9 @@ struct TileX {
 #ifndef SICN_XW_STAGGER
 #define SICN_XW_STAGGER 8
 #endif
-__device__ __forceinline__ void stagger_x()
+__device__ __forceinline__ void stagger_x(int n_xcd)
 {
-    const int slot = ((int)blockIdx.x / N_XCD) & 31;
+    const int slot = ((int)blockIdx.x / n_xcd) & 31;
     for (int i = 0; i < slot * SICN_XW_STAGGER; i++) __builtin_amdgcn_s_sleep(1);   // 64 cycles each
 }
 
@@ -451,7 +451,7 @@ constexpr int SWITCH_T = 25 + 16;                 // from this pass of a tile on
 template <bool NT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_conv_x(
     const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int8_t *__restrict__ wstream, const int8_t *__restrict__ bias_g, int IW,
-    int IH, int OW, int OH, int tiles_x, int n_tiles, int n_images, int in_layout, int out_layout, uint32_t act_floor)
+    int IH, int OW, int OH, int tiles_x, int n_tiles, int n_images, int in_layout, int out_layout, uint32_t act_floor, int n_xcd)
 {
     constexpr int CIN = 128, COUT = 128;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -461,14 +461,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bool hi = (g >> 1) != 0;
     const int in_img_bytes = IH * IW * CIN, out_img_bytes = OH * OW * COUT;
     const TensorMap im = tensor_map(in_layout, CIN, IW, IH), om = tensor_map(out_layout, COUT, OW, OH);
-    // this workgroup's tiles: XCD x = l % 8 owns [x * per, (x + 1) * per) of the (tile x, tile y, image) list; its gridDim.x / 8
+    // this workgroup's tiles: XCD x = l % n_xcd owns [x * per, (x + 1) * per) of the (tile x, tile y, image) list; its gridDim.x / 8
     // workgroups take every (gridDim.x / 8)-th one — neighbours in the list run on one XCD at about the same time
-    const int total = n_tiles * n_images, per = (total + N_XCD - 1) / N_XCD;
-    const int xcd = (int)blockIdx.x % N_XCD, stride = (int)gridDim.x / N_XCD;
-    int item = xcd * per + (int)blockIdx.x / N_XCD;
+    const int total = n_tiles * n_images, per = (total + n_xcd - 1) / n_xcd;
+    const int xcd = (int)blockIdx.x % n_xcd, stride = (int)gridDim.x / n_xcd;
+    int item = xcd * per + (int)blockIdx.x / n_xcd;
     const int item_end = min(total, (xcd + 1) * per);
     if (item >= item_end) return;   // before any barrier or request
-    stagger_x();
+    stagger_x(n_xcd);
     auto coord = [&](int it) {
         const int img = it / n_tiles, tile = it - img * n_tiles, ty = tile / tiles_x;
         return TileX{img, ty * TY, (tile - ty * tiles_x) * TX};
@@ -740,7 +740,7 @@ __device__ __forceinline__ void deconv_pass_x(v4i (&acc)[8][8], const v4i (&pc)[
 template <bool NT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_deconv_x(
     const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int8_t *__restrict__ wstream, const int8_t *__restrict__ bias_g, int IW,
-    int IH, int OW, int OH, int tiles_x, int n_tiles, int n_images, int in_layout, int out_layout, uint32_t act_floor)
+    int IH, int OW, int OH, int tiles_x, int n_tiles, int n_images, int in_layout, int out_layout, uint32_t act_floor, int n_xcd)
 {
     constexpr int CIN = 128, COUT = 128;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -750,12 +750,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bool hi = (g >> 1) != 0;
     const int in_img_bytes = IH * IW * CIN, out_img_bytes = OH * OW * COUT;
     const TensorMap im = tensor_map(in_layout, CIN, IW, IH), om = tensor_map(out_layout, COUT, OW, OH);
-    const int total = n_tiles * n_images, per = (total + N_XCD - 1) / N_XCD;
-    const int xcd = (int)blockIdx.x % N_XCD, stride = (int)gridDim.x / N_XCD;
-    int item = xcd * per + (int)blockIdx.x / N_XCD;
+    const int total = n_tiles * n_images, per = (total + n_xcd - 1) / n_xcd;
+    const int xcd = (int)blockIdx.x % n_xcd, stride = (int)gridDim.x / n_xcd;
+    int item = xcd * per + (int)blockIdx.x / n_xcd;
     const int item_end = min(total, (xcd + 1) * per);
     if (item >= item_end) return;
-    stagger_x();
+    stagger_x(n_xcd);
     auto coord = [&](int it) {
         const int img = it / n_tiles, tile = it - img * n_tiles, ty = tile / tiles_x;
         return TileX{img, ty * TY, (tile - ty * tiles_x) * TX};
@@ -955,7 +955,7 @@ void pack_mfma16x_deconv_stream(const int8_t *w_okc, int cin, int cout, int8_t *
 bool wide_supported(const LayerGeom &g) { return g.CIN == 128 && g.COUT == 128; }
 
 hipError_t launch_wide(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images, hipStream_t stream,
-                       int in_layout, int out_layout, bool relu, int grid_cap)
+                       int in_layout, int out_layout, bool relu, int grid_cap, const ChipGeom &chip)
 {
     using namespace xw;
     if (!wide_supported(g)) return hipErrorInvalidValue;
@@ -967,8 +967,7 @@ hipError_t launch_wide(const LayerGeom &g, const sicn_weights &w, const uint8_t 
     if (total <= 0 || total > 0x7fffffffL) return hipErrorInvalidValue;
     const uint32_t flags = relu ? ACT_FLOOR_RELU : ACT_FLOOR_RAW;
     const bool nt = nt_store_wanted((size_t)g.OH * g.OW * g.COUT * n_images);
-    const long cap = grid_cap > 0 ? std::max(N_XCD, grid_cap / N_XCD * N_XCD) : 256;              // one resident per CU
-    const unsigned grid = (unsigned)std::min<long>(cap, (total + N_XCD - 1) / N_XCD * N_XCD);      // a multiple of 8
+    const unsigned grid = wide_grid(total, grid_cap, chip);   // one resident per CU, a multiple of the XCD count (sicn_plan.h)
     const void *fn = g.transposed ? (nt ? (const void *)&k_deconv_x<true> : (const void *)&k_deconv_x<false>)
                                   : (nt ? (const void *)&k_conv_x<true> : (const void *)&k_conv_x<false>);
     const size_t lds = g.transposed ? DECONV_LDS : CONV_LDS;
@@ -977,7 +976,8 @@ hipError_t launch_wide(const LayerGeom &g, const sicn_weights &w, const uint8_t 
     const int8_t *ws = g.transposed ? w.d_w_mfma16x : w.d_w_mfma16;
     int IW = g.IW, IH = g.IH, OW = g.OW, OH = g.OH, n_tiles = tiles_x * tiles_y, txs = tiles_x;
     uint32_t fl = flags;
-    void *args[] = {(void *)&in, (void *)&out, (void *)&ws, (void *)&w.d_bias, &IW, &IH, &OW, &OH, &txs, &n_tiles, &n_images, &in_layout, &out_layout, &fl};
+    int n_xcd = chip.n_xcd;
+    void *args[] = {(void *)&in, (void *)&out, (void *)&ws, (void *)&w.d_bias, &IW, &IH, &OW, &OH, &txs, &n_tiles, &n_images, &in_layout, &out_layout, &fl, &n_xcd};
     e = hipLaunchKernel(fn, dim3(grid), dim3(256), args, lds, stream);
     if (e != hipSuccess) return e;
     return hipGetLastError();

@@ -221,17 +221,13 @@ void pack_l0(const int8_t *w_okc, int cout, int8_t *dst)
 }
 
 hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream, int out_layout, const sicn_options &o, bool relu)
+                     int n_images, hipStream_t stream, int out_layout, const sicn_options &o, const ChipGeom &chip, bool relu)
 {
     const int tiles_x = (g.OW + TILE_X - 1) / TILE_X, tiles_y = (g.OH + L0_TY - 1) / L0_TY;
-    // runs of at most L0_CHUNK tiles (the LDS holds a run's pixels), evened out; the test hook can only shorten them
-    int y_chunks = (tiles_y + L0_CHUNK - 1) / L0_CHUNK;
-    int want = (1024 + tiles_x * n_images - 1) / (tiles_x * n_images);   // small images: shorter runs, enough workgroups
-    const int forced = o.strip_chunks;
-    if (forced > 0) want = forced;
-    if (want > y_chunks) y_chunks = want > tiles_y ? tiles_y : want;
-    const int ty_per = (tiles_y + y_chunks - 1) / y_chunks;
-    y_chunks = (tiles_y + ty_per - 1) / ty_per;
+    // runs of at most L0_CHUNK tiles (the LDS holds a run's pixels), evened out; small images: shorter runs, enough workgroups
+    // (about four per CU, sicn_plan.h); the test hook (strip_chunks) can only shorten them
+    const L0Cut cut = l0_chunks(tiles_x, tiles_y, n_images, L0_CHUNK, o.strip_chunks, chip);
+    const int y_chunks = cut.y_chunks, ty_per = cut.ty_per;
     dim3 grid((unsigned)tiles_x, (unsigned)y_chunks, (unsigned)n_images);
     if ((size_t)g.IH * g.IW * 3 * (size_t)n_images + 4 >= (size_t)OOB) return hipErrorInvalidValue;
     if ((size_t)g.OH * g.OW * g.COUT >= (size_t)OOB) return hipErrorInvalidValue;   // buffer-descriptor stores
@@ -334,7 +330,7 @@ __device__ unsigned long long g_l7_stamp[8];
 __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                const int8_t *__restrict__ w_l7,
                                                const int8_t *__restrict__ bias, int IW, int IH, int OW,
-                                               int OH, int steps_y, int y_chunks, int tiles_x, int n_images, int in_layout)
+                                               int OH, int steps_y, int y_chunks, int tiles_x, int n_images, int in_layout, int n_xcd)
 {
     constexpr int CIN = 128;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -345,7 +341,7 @@ __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // logical work list: strip (fastest), chunk, image — an XCD gets whole rows of neighbouring strips
-    const int item = xcd_logical_index(tiles_x * y_chunks * n_images);
+    const int item = xcd_logical_index(tiles_x * y_chunks * n_images, n_xcd);
     if (item < 0) return;
     const int bx = item % tiles_x, by = (item / tiles_x) % y_chunks, img = item / (tiles_x * y_chunks);
     const int X0 = bx * TILE_X;
@@ -544,25 +540,23 @@ void pack_l7(const int8_t *w_okc, int cin, int8_t *dst)
 }
 
 hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream, int in_layout, const sicn_options &o)
+                     int n_images, hipStream_t stream, int in_layout, const sicn_options &o, const ChipGeom &chip)
 {
     if (g.CIN != 128 || g.COUT != 3) return hipErrorInvalidValue;
     if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB) return hipErrorInvalidValue;
     if ((size_t)g.OH * g.OW * 3 >= (size_t)OOB) return hipErrorInvalidValue;   // buffer-descriptor stores
     const int tiles_x = (g.IW + TILE_X - 1) / TILE_X, steps_y = (g.IH + L7_ROWS - 1) / L7_ROWS;
-    int y_chunks = o.strip_chunks;
-    // about 512 workgroups in all (two per CU; three would fit) — measured
+    // about two workgroups per CU in all (three would fit) — measured
     // r02 (tools/strip_sweep.py): 1080p x 1 best at 16 - 24 chunks of 30 strips, x 4 at 4 - 6 of 120, 4K x 8 at 1 of 480;
     // every extra chunk re-fetches six halo rows and re-loads the 18 KB of weights
     // (r03, re-measured on one 1080p image, 30 strips: 13 / 15 / 17 / 19 / 21 / 25 chunks -> 23 / 22 / 19 / 24 / 23 / 21 us: the best
     // cut is the one that stays just under TWO workgroups per CU, 510 of 512; the 640 of round 2 was the middle of a flat region)
-    if (y_chunks <= 0) y_chunks = 512 / (tiles_x * n_images);
-    y_chunks = y_chunks < 1 ? 1 : (y_chunks > steps_y ? steps_y : y_chunks);
+    const int y_chunks = l7_chunks(tiles_x, n_images, steps_y, o.strip_chunks, chip);
     const size_t lds = 2 * L7_REGION + 4 * L7_STAGE + 1024;
     hipError_t e = hipFuncSetAttribute((const void *)k_l7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_l7, dim3(xcd_grid_size(tiles_x * y_chunks * n_images)), dim3(256), lds, stream, in, out, w.d_w_l7,
-                       w.d_bias, g.IW, g.IH, g.OW, g.OH, steps_y, y_chunks, tiles_x, n_images, in_layout);
+    hipLaunchKernelGGL(k_l7, dim3(xcd_grid_size((long)tiles_x * y_chunks * n_images, chip.n_xcd)), dim3(256), lds, stream, in, out, w.d_w_l7,
+                       w.d_bias, g.IW, g.IH, g.OW, g.OH, steps_y, y_chunks, tiles_x, n_images, in_layout, chip.n_xcd);
     return hipGetLastError();
 }
 

@@ -6,7 +6,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
+#include <random>
 #include <vector>
 
 #include "sicn_gdn_internal.h"
@@ -37,6 +39,7 @@ const sicn_options &default_options()
         d.split_n = env_int("SICN_SPLIT_N");
         d.wave_tile = env_int("SICN_WAVE_TILE");
         d.prefetch = env_int("SICN_PREFETCH");
+        d.split_k = env_int("SICN_SPLIT_K");
         // the same range checks a caller's struct gets (resolve_options): an out-of-range variable is ignored, loudly, once
         auto bad = [](const char *name, int32_t &v) {
             fprintf(stderr, "libsicn: ignoring out-of-range %s=%d\n", name, (int)v);
@@ -52,10 +55,38 @@ const sicn_options &default_options()
         if (d.split_n < 0 || d.split_n > 4) bad("SICN_SPLIT_N", d.split_n);
         if (d.wave_tile != 0 && d.wave_tile != 64 && d.wave_tile != 128) bad("SICN_WAVE_TILE", d.wave_tile);
         if (d.prefetch < 0 || d.prefetch > 3) bad("SICN_PREFETCH", d.prefetch);
+        if (d.split_k < 0 || d.split_k > 4) bad("SICN_SPLIT_K", d.split_k);
         return d;
     }();
     return o;
 }
+// Geometry of the current device, read once per device ordinal from hipDeviceProp_t (immutable afterwards).  The code objects in
+// this library are gfx950 only: any other architecture is SICN_ENODEV here, with one line on stderr, instead of a failed code
+// object load at the first launch (the reference's error path is exit(-1), bnn-library.h:55).  SICN_N_CU (read at load) overrides
+// the CU count — experiments only: e.g. what the launch planning of a 128-CU partition does on a whole chip.
+int chip_geom(ChipGeom *out)
+{
+    constexpr int MAX_DEV = 64;
+    struct Entry { std::once_flag once; int rc = SICN_ENODEV; ChipGeom geom{1, 1}; };
+    static Entry table[MAX_DEV];
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return SICN_ENODEV;
+    Entry &e = table[dev];
+    std::call_once(e.once, [&] {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return;
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            fprintf(stderr, "libsicn: device %d is %s; this library holds gfx950 (MI355X) kernels only\n", dev, prop.gcnArchName);
+            return;
+        }
+        static const int forced_cu = env_int("SICN_N_CU");
+        e.geom = chip_from_cus(forced_cu > 0 ? forced_cu : prop.multiProcessorCount);
+        e.rc = SICN_OK;
+    });
+    if (e.rc == SICN_OK && out) *out = e.geom;
+    return e.rc;
+}
+
 const DebugEnv &debug_env()
 {
     static const DebugEnv d{env_int("SICN_MFMA_VARIANT"), env_int("SICN_DEBUG_KERNEL"), env_int("SICN_DEBUG_EXTRA_LDS")};
@@ -82,6 +113,7 @@ static int resolve_options(const sicn_options *in, sicn_options *out)
     if (o.split_n < 0 || o.split_n > 4) return SICN_EINVAL;
     if (o.wave_tile != 0 && o.wave_tile != 64 && o.wave_tile != 128) return SICN_EINVAL;
     if (o.prefetch < 0 || o.prefetch > 3 || o.persistent_grid < 0) return SICN_EINVAL;
+    if (o.split_k < 0 || o.split_k > 4) return SICN_EINVAL;
     *out = o;
     return SICN_OK;
 }
@@ -91,7 +123,9 @@ extern "C" void sicn_options_init(sicn_options *opt)
     if (opt) *opt = default_options();
 }
 
-extern "C" int sicn_version(void) { return 1000 * 0 + 1; }
+// 0.2: sicn_options.split_k (a reserved slot), sicn_net_workspace_bytes grows by the K-split scratch, sicn_codec_info.struct_bytes,
+// SICN_ENODEV for a device that is not gfx950
+extern "C" int sicn_version(void) { return 1000 * 0 + 2; }
 
 extern "C" int sicn_has_alt_kernels(void)
 {
@@ -108,7 +142,7 @@ extern "C" const char *sicn_strerror(int code)
     case SICN_OK: return "ok";
     case SICN_EINVAL: return "invalid descriptor or argument";
     case SICN_ENOMEM: return "out of memory";
-    case SICN_ENODEV: return "HIP device/runtime error";
+    case SICN_ENODEV: return "no gfx950 device, or HIP runtime error";
     case SICN_ENOSPC: return "workspace too small";
     default: return "unknown error";
     }
@@ -194,6 +228,7 @@ extern "C" int sicn_weights_from_finn_tiles(const sicn_layer_desc *d, const void
     *out = nullptr;
     int rc = validate_weights_fields(d);
     if (rc || !m_weights || !bias) return SICN_EINVAL;
+    if (chip_geom(nullptr) != SICN_OK) return SICN_ENODEV;   // no device, or not a gfx950 one: refuse before anything is uploaded
     if (word_bytes != 1 && word_bytes != 2 && word_bytes != 4 && word_bytes != 8) return SICN_EINVAL;
     if (d->SIMD * 4 > word_bytes * 8) return SICN_EINVAL;
     const int cin = d->IFM_CH, cout = d->OFM_CH, simd = d->SIMD, pe_n = d->PE, tiles = d->W_TILES;
@@ -301,7 +336,7 @@ static int link_layout(const sicn_layer_desc &p, const sicn_layer_desc &c, const
 // place, in whatever layout the layer wrote (include/sicn_gdn.h; extension beyond the reference).
 static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint8_t *in, uint8_t *out,
                      int n_images, hipStream_t stream, int want_transposed, const sicn_options &o, int in_layout = 0,
-                     int out_layout = 0, const sicn_gdn *gdn = nullptr)
+                     int out_layout = 0, const sicn_gdn *gdn = nullptr, const KSplitScratch *ks = nullptr)
 {
     int rc = sicn_validate_desc(d);
     if (rc) return rc;
@@ -313,10 +348,12 @@ static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint
     if (gdn && gdn->channels != d->OFM_CH) return SICN_EINVAL;
     const LayerGeom g = geom_of(*d);
     const bool relu = gdn == nullptr;
+    ChipGeom chip;
+    if ((rc = chip_geom(&chip)) != SICN_OK) return rc;   // no device, or not a gfx950 one
     hipError_t e;
     switch (layer_kernel(*d, o, gdn != nullptr)) {
-    case KK_L0_RGB: e = launch_l0(g, *w, in, out, n_images, stream, out_layout, o, relu); break;
-    case KK_L7_RGB: e = launch_l7(g, *w, in, out, n_images, stream, in_layout, o); break;
+    case KK_L0_RGB: e = launch_l0(g, *w, in, out, n_images, stream, out_layout, o, chip, relu); break;
+    case KK_L7_RGB: e = launch_l7(g, *w, in, out, n_images, stream, in_layout, o, chip); break;
     case KK_MFMA_CONV:
     case KK_MFMA_DECONV:
         // MFMA shape: 16x16x64 by default (higher sustained clock, k_mfma16.hip); mfma_shape = 32 selects
@@ -327,7 +364,7 @@ static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint
             break;
         }
 #endif
-        e = launch_mfma16(g, *w, in, out, n_images, stream, in_layout, out_layout, o, relu);
+        e = launch_mfma16(g, *w, in, out, n_images, stream, in_layout, out_layout, o, chip, relu, ks);
         break;
     default: e = launch_generic(g, *w, in, out, n_images, stream, relu); break;
     }
@@ -370,6 +407,7 @@ struct sicn_net {
     std::vector<const sicn_weights *> weights;
     std::vector<const sicn_gdn *> gdn;         // per layer, nullptr = the reference's ReLU
     sicn_options opt;                          // fixed at creation
+    unsigned long long ks_tag;                 // K-split arrival words of this net carry this random tag (k_mfma16p.hip); low byte 0
     // profiling: the only state a launch changes.  One flat ring of event pairs; a forward call reserves the
     // slots of its layers with one atomic fetch_add, so calls on several streams / threads never share a slot.
     static constexpr int EV_RING = 8192;
@@ -423,7 +461,11 @@ extern "C" int sicn_net_create_gdn(const sicn_layer_desc *descs, sicn_weights *c
         net->gdn.assign((size_t)n_layers, nullptr);
         if (gdn) net->gdn.assign(gdn, gdn + n_layers);
         net->opt = o;
-    } catch (const std::bad_alloc &) {
+        std::random_device rd;
+        do {
+            net->ks_tag = (((unsigned long long)rd() << 32) | (unsigned long long)rd()) & ~0xffull;
+        } while (net->ks_tag == 0);
+    } catch (const std::exception &) {
         delete net;
         return SICN_ENOMEM;
     }
@@ -447,10 +489,36 @@ static size_t pingpong_slot_bytes(const sicn_net *net, int n_images)
     return align256(mx * (size_t)n_images);
 }
 
+// K-split scratch behind the ping-pong buffers (k_mfma16p.hip): KSPLIT_MAX partial tensors of the largest output any layer of the
+// chain would compute K-split on this chip, and one arrival word per workgroup of the largest such grid.  Small by construction:
+// the split is only taken by grids of at most half a workgroup per CU.
+struct KsNeed { size_t partial, words; };
+static KsNeed ksplit_need(const sicn_net *net, int n_images, const ChipGeom &chip)
+{
+    KsNeed n{0, 0};
+    for (size_t l = 0; l < net->descs.size(); l++) {
+        const sicn_layer_desc &d = net->descs[l];
+        const KernelKind k = pick_kernel(d, net->opt);
+        if (k != KK_MFMA_CONV && k != KK_MFMA_DECONV) continue;
+        const MfmaPlan p = plan_mfma(geom_of(d), n_images, net->opt, chip);
+        if (p.split_k <= 1) continue;
+        const size_t ob = align256(out_bytes(d) * (size_t)n_images), words = (size_t)p.grid_x * p.grid_y;
+        n.partial = n.partial > ob ? n.partial : ob;
+        n.words = n.words > words ? n.words : words;
+    }
+    return n;
+}
+static ChipGeom chip_or_default()
+{
+    ChipGeom c;
+    return chip_geom(&c) == SICN_OK ? c : chip_from_cus(256);   // sizes can be asked for without a device: the whole MI355X
+}
+
 extern "C" size_t sicn_net_workspace_bytes(const sicn_net *net, int n_images)
 {
     if (!net || n_images <= 0) return 0;
-    return 2 * pingpong_slot_bytes(net, n_images);
+    const KsNeed ks = ksplit_need(net, n_images, chip_or_default());
+    return 2 * pingpong_slot_bytes(net, n_images) + KSPLIT_MAX * ks.partial + align256(ks.words * sizeof(unsigned long long));
 }
 
 extern "C" int sicn_net_forward(const sicn_net *net, int first, int last, const uint8_t *in, uint8_t *out,
@@ -466,6 +534,26 @@ extern "C" int sicn_net_forward(const sicn_net *net, int first, int last, const 
     if (last > first && (!workspace || workspace_bytes < 2 * slot)) return SICN_ENOSPC;
     hipStream_t stream = (hipStream_t)hip_stream;
     uint8_t *pp[2] = {(uint8_t *)workspace, (uint8_t *)workspace + slot};
+    // K-split scratch: behind the ping-pong buffers when the workspace is of the size sicn_net_workspace_bytes asks for.  A smaller
+    // (older-sized) or absent workspace only switches the automatic split off; a forced one (options.split_k > 1) is SICN_ENOSPC.
+    KSplitScratch ks_store{nullptr, 0, nullptr, 0, net->ks_tag};
+    const KSplitScratch *ks = nullptr;
+    {
+        ChipGeom chip;
+        if (int rc = chip_geom(&chip)) return rc;
+        const KsNeed need = ksplit_need(net, n_images, chip);
+        if (need.partial) {
+            const size_t total = 2 * slot + KSPLIT_MAX * need.partial + align256(need.words * sizeof(unsigned long long));
+            if (workspace && workspace_bytes >= total) {
+                ks_store.partials = (uint8_t *)workspace + 2 * slot;
+                ks_store.partial_stride = need.partial;
+                ks_store.flags = (unsigned long long *)((uint8_t *)workspace + 2 * slot + KSPLIT_MAX * need.partial);
+                ks_store.n_flags = need.words;
+                ks = &ks_store;
+            } else if (net->opt.split_k > 1)
+                return SICN_ENOSPC;
+        }
+    }
     const uint8_t *cur = in;
     int cur_layout = 0;  // the chain's input is always NHWC
     // profiling: reserve this call's event slots (one per layer) in one atomic step
@@ -476,7 +564,9 @@ extern "C" int sicn_net_forward(const sicn_net *net, int first, int last, const 
         if (at + need <= sicn_net::EV_RING) slot0 = at;   // ring full: this call is not timed
     }
     for (int l = first; l <= last; l++) {
-        uint8_t *dst = (l == last) ? out : pp[(l - first) & 1];
+        // a tapped layer (the latent) is written straight into the caller's buffer and the next layer reads it there: no copy
+        // (round 3 copied it device-to-device behind the layer: 4.8 us per forward pass on small inputs, 15 us on 8 x 4K)
+        uint8_t *dst = (l == last) ? out : (l == tap_layer ? tap_out : pp[(l - first) & 1]);
         // intermediates nobody outside sees travel in the grouped layout when both neighbours can
         const int out_layout = (l < last && l != tap_layer)
                                    ? link_layout(net->descs[l], net->descs[l + 1], net->opt, net->gdn[l] != nullptr, net->gdn[l + 1] != nullptr)
@@ -487,7 +577,7 @@ extern "C" int sicn_net_forward(const sicn_net *net, int first, int last, const 
             if (hipEventRecord(net->ev_begin[slot], stream) != hipSuccess) return SICN_ENODEV;
         }
         int rc = run_layer(&net->descs[l], net->weights[l], cur, dst, n_images, stream, -1, net->opt, cur_layout, out_layout,
-                           net->gdn[l]);
+                           net->gdn[l], ks);
         if (rc) return rc;
         if (slot >= 0) {
             if (hipEventRecord(net->ev_end[slot], stream) != hipSuccess) return SICN_ENODEV;
@@ -570,6 +660,41 @@ extern "C" int sicn_net_layer_ms(sicn_net *net, int reset, float *ms_sum, int *l
         net->ev_next.store(0, std::memory_order_release);
     }
     return SICN_OK;
+}
+
+// ---- launch planning, inspectable without a GPU (tests/test_abi_load.py): what would this layer launch on a chip of n_cu CUs? ----
+extern "C" int sicn_debug_plan(const sicn_layer_desc *d, int n_images, const sicn_options *opt, int n_cu, int32_t out[12])
+{
+    sicn_options o;
+    if (int rc = resolve_options(opt, &o)) return rc;
+    if (int rc = sicn_validate_desc(d)) return rc;
+    if (!out || n_images <= 0 || n_cu <= 0) return SICN_EINVAL;
+    const ChipGeom chip = chip_from_cus(n_cu);
+    const LayerGeom g = geom_of(*d);
+    for (int i = 0; i < 12; i++) out[i] = 0;
+    out[0] = chip.n_cu;
+    out[1] = chip.n_xcd;
+    const KernelKind k = pick_kernel(*d, o);
+    out[2] = (int)k;
+    if (k == KK_MFMA_CONV || k == KK_MFMA_DECONV) {
+        const MfmaPlan p = plan_mfma(g, n_images, o, chip);
+        out[3] = p.family; out[4] = p.tile_x; out[5] = p.split_n; out[6] = p.split_k;
+        out[7] = (int)p.grid_x; out[8] = (int)p.grid_y; out[9] = (int)p.grid_z;
+    } else if (k == KK_L7_RGB) {
+        const int tiles_x = (g.IW + 31) / 32, steps_y = (g.IH + 3) / 4;
+        const int yc = l7_chunks(tiles_x, n_images, steps_y, o.strip_chunks, chip);
+        out[7] = (int)xcd_grid_size((long)tiles_x * yc * n_images, chip.n_xcd); out[8] = 1; out[9] = 1; out[10] = yc;
+    } else if (k == KK_L0_RGB) {
+        const int tiles_x = (g.OW + 31) / 32, tiles_y = (g.OH + 7) / 8;
+        const L0Cut c = l0_chunks(tiles_x, tiles_y, n_images, 9, o.strip_chunks, chip);
+        out[7] = tiles_x; out[8] = c.y_chunks; out[9] = n_images; out[10] = c.y_chunks; out[11] = c.ty_per;
+    }
+    return SICN_OK;
+}
+// host mirror of the kernels' XCD-aware work list: the item of workgroup `block`, or -1 (a bijection for every XCD count)
+extern "C" long long sicn_debug_xcd_item(long long block, long long n_items, int n_xcd)
+{
+    return n_xcd > 0 ? (long long)xcd_item_of((long)block, (long)n_items, n_xcd) : -1;
 }
 
 // ---- GDN / IGDN activation objects (include/sicn_gdn.h; extension beyond the reference) ------------------------

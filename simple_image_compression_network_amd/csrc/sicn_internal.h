@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/sicn.h"
+#include "sicn_plan.h"
 
 namespace sicn {
 
@@ -52,13 +53,45 @@ struct sicn_weights {
 namespace sicn {
 
 KernelKind pick_kernel(const sicn_layer_desc &d, const sicn_options &o);
+
+// Scratch of a K-split launch (k_mfma16p.hip): `slices` partial tensors of the layer's output size each and the flag words of
+// the tiles, inside the caller's workspace; nonce: see sicn_abi.hip (ksplit_nonce)
+struct KSplitScratch {
+    uint8_t *partials;          // [slices][n_images * out_bytes]
+    size_t partial_stride;      // bytes between two slices' tensors
+    unsigned long long *flags;  // [workgroups of the unsplit grid][KSPLIT_MAX]
+    size_t n_flags;             // capacity in flag words
+    unsigned long long nonce;
+};
+constexpr int KSPLIT_MAX = 3;   // 192 input channels = 3 channel-group pairs
+
+// what plan_mfma (k_mfma16.hip) decides for a conv / deconv layer of the 128 / 192-channel shapes
+struct MfmaPlan {
+    int family;      // 0: k_mfma16_t, 1: the software-pipelined kernels (k_mfma16p.hip), 2: the wide persistent kernels (k_mfma16x.hip)
+    int tile_x;      // 16 | 32 (families 0, 1)
+    int split_n;     // output-channel slices (workgroups of blockIdx.y), 1 = none
+    int split_k;     // K slices (blockIdx.z), 1 = none
+    unsigned grid_x, grid_y, grid_z;
+};
+MfmaPlan plan_mfma(const LayerGeom &g, int n_images, const sicn_options &o, const ChipGeom &chip);
+// does `ks` hold the partial tensors and flag words the plan's K split needs?
+inline bool ksplit_scratch_fits(const LayerGeom &g, int n_images, const MfmaPlan &p, const KSplitScratch *ks)
+{
+    if (!ks || !ks->partials || !ks->flags) return false;
+    const size_t out_bytes = (size_t)g.OH * g.OW * g.COUT * (size_t)n_images;
+    return ks->partial_stride >= out_bytes && ks->n_flags >= (size_t)p.grid_x * p.grid_y;
+}
 // library defaults: zeros overridden by the SICN_* environment as it was at load time (read once)
 const sicn_options &default_options();
 // build-time experiment switches of k_mfma.hip (SICN_MFMA_VARIANT, SICN_DEBUG_KERNEL, SICN_DEBUG_EXTRA_LDS), read once
 struct DebugEnv { int mfma_variant, debug_kernel, extra_lds; };
 const DebugEnv &debug_env();
 
-// Launchers: enqueue on `stream`, return hipError_t of the launch.
+// Geometry of the CURRENT device (hipGetDevice), read once per device from hipDeviceProp_t: SICN_OK, or SICN_ENODEV when there
+// is no device or it is not a gfx950 part (the code objects of this library exist for gfx950 only)
+int chip_geom(ChipGeom *out);
+
+// Launchers: enqueue on `stream`, return hipError_t of the launch.  `chip`: sizes every grid (sicn_plan.h).
 // relu = false: store the lane BEFORE the sign-bit ReLU (input of the GDN extension, include/sicn_gdn.h)
 hipError_t launch_generic(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
                           int n_images, hipStream_t stream, bool relu = true);
@@ -66,23 +99,24 @@ hipError_t launch_generic(const LayerGeom &g, const sicn_weights &w, const uint8
 hipError_t launch_mfma(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
                        int n_images, hipStream_t stream, int in_layout, int out_layout);
 hipError_t launch_mfma16(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                         int n_images, hipStream_t stream, int in_layout, int out_layout, const sicn_options &o, bool relu = true);
+                         int n_images, hipStream_t stream, int in_layout, int out_layout, const sicn_options &o, const ChipGeom &chip,
+                         bool relu = true, const KSplitScratch *ks = nullptr);
 // k_mfma16x.hip: the wide persistent form — one workgroup of 4 waves per CU walks through 16 x 32-position tiles, 128 x 128 outputs
 // per wave (accumulators in AGPRs, one wave per SIMD); grid_cap > 0 limits the number of workgroups (tests)
-constexpr int WIDE_MIN_TILES = 4;   // automatic from this many tiles per CU on
 bool wide_supported(const LayerGeom &g);
 size_t mfma16x_deconv_stream_bytes(int cin, int cout);   // 0 where the wide deconv does not exist
 void pack_mfma16x_deconv_stream(const int8_t *w_okc, int cin, int cout, int8_t *dst);
 hipError_t launch_wide(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images, hipStream_t stream,
-                       int in_layout, int out_layout, bool relu, int grid_cap);
+                       int in_layout, int out_layout, bool relu, int grid_cap, const ChipGeom &chip);
 // k_mfma16p.hip: the software-pipelined conv / deconv kernels (tile_x = 16 | 32)
 bool pipelined_supported(const LayerGeom &g, int tile_x);
 hipError_t launch_pipelined(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,
-                            hipStream_t stream, int in_layout, int out_layout, bool relu, int tile_x, bool split_channels);
+                            hipStream_t stream, int in_layout, int out_layout, bool relu, int tile_x, bool split_channels,
+                            const ChipGeom &chip, int split_k = 1, const KSplitScratch *ks = nullptr);
 hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream, int out_layout, const sicn_options &o, bool relu = true);
+                     int n_images, hipStream_t stream, int out_layout, const sicn_options &o, const ChipGeom &chip, bool relu = true);
 hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
-                     int n_images, hipStream_t stream, int in_layout, const sicn_options &o);
+                     int n_images, hipStream_t stream, int in_layout, const sicn_options &o, const ChipGeom &chip);
 
 // Host-side weight packers (pure CPU, unit-testable without a GPU).
 // w_okc: [cout][25*cin].  Returns bytes written into `dst` (size from *_bytes()).

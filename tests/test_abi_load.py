@@ -81,7 +81,7 @@ def test_options_defaults_and_validation_without_gpu():
     out = ctypes.c_void_p()
     assert L.sicn_has_alt_kernels() == 0       # the product build: the alternate kernel families are in libsicn_alt.so only
     for field, bad in (("mfma_shape", 8), ("mfma_shape", 32), ("tile_x", 24), ("strip_chunks", -1), ("no_phase_layout", 3), ("split_n", 7),
-                       ("struct_bytes", 4), ("struct_bytes", 4096)):
+                       ("split_k", 9), ("struct_bytes", 4), ("struct_bytes", 4096)):
         o = _lib.make_options()
         setattr(o, field, bad)
         assert L.sicn_conv2d_opt(ctypes.byref(d), None, None, None, 1, ctypes.byref(o), None) == -22
@@ -101,3 +101,63 @@ def test_isa_hazard_checker_flags_the_known_bugs():
     r = subprocess.run([sys.executable, str(root / "tools" / "isa_hazards.py"), "--selftest"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok ") == 5 and "FAIL" not in r.stdout
+
+
+def _plan(d, n_images, n_cu, **opts):
+    L = _lib.lib()
+    out = (ctypes.c_int32 * 12)()
+    o = _lib.make_options(**opts)
+    assert L.sicn_debug_plan(ctypes.byref(d.to_c()), n_images, ctypes.byref(o), n_cu, out) == 0
+    keys = ("n_cu", "n_xcd", "kind", "family", "tile_x", "split_n", "split_k", "gx", "gy", "gz", "chunks", "ty_per")
+    return dict(zip(keys, list(out)))
+
+
+def test_launch_planning_follows_the_chip_size_without_gpu():
+    """Nothing in csrc/ hard-wires 256 CUs / 8 XCDs: grids, strip cuts, the wide / narrow / split choices
+    come from sicn_plan.h as functions of the device's CU count.  Walked here for a whole MI355X (256), a DPX partition (128)
+    and a CPX partition (32), no GPU needed."""
+    from simple_image_compression_network_amd.config import eight_layer_descs
+    L = _lib.lib()
+    # XCD rule and the work-list mapping: a bijection onto the items for every XCD count, padding workgroups get -1
+    for n_cu, n_xcd in ((256, 8), (240, 8), (304, 8), (128, 4), (64, 2), (32, 1), (36, 1), (1, 1)):
+        assert _plan(eight_layer_descs(256, 256)[0], 1, n_cu)["n_xcd"] == n_xcd
+    for n_xcd in (1, 2, 4, 8):
+        for n_items in (1, 7, 8, 9, 255, 1000):
+            grid = (n_items + n_xcd - 1) // n_xcd * n_xcd
+            items = [L.sicn_debug_xcd_item(b, n_items, n_xcd) for b in range(grid)]
+            assert sorted(i for i in items if i >= 0) == list(range(n_items))
+            assert items.count(-1) == grid - n_items
+    d4k = eight_layer_descs(3840, 2160)
+    # 8 x 4K: layers 1, 2, 5, 6 on the wide persistent kernels, ONE workgroup per CU of whatever chip this is
+    for n_cu in (256, 128, 32):
+        for l in (1, 2, 5, 6):
+            p = _plan(d4k[l], 8, n_cu)
+            assert p["family"] == 2 and p["gx"] == n_cu, (n_cu, l, p)
+        p7 = _plan(d4k[7], 8, n_cu)                     # 60 strips x 8 images = 480 workgroups: never cut, grid padded to the XCD count
+        assert p7["chunks"] == 1 and p7["gx"] % p7["n_xcd"] == 0 and p7["gx"] == 480
+    # one 1080p image: the wide conv needs >= 3.5 full rounds of the CUs -> not on 256, but on a 32-CU partition
+    d1080 = eight_layer_descs(1920, 1080)
+    assert _plan(d1080[1], 1, 256)["family"] == 1 and _plan(d1080[1], 1, 256)["tile_x"] == 32
+    assert _plan(d1080[1], 1, 32)["family"] == 2 and _plan(d1080[1], 1, 32)["gx"] == 32
+    # layer 7 strips of one 1080p image: about two workgroups per CU in all
+    assert _plan(d1080[7], 1, 256)["chunks"] == 512 // 30
+    assert _plan(d1080[7], 1, 128)["chunks"] == 256 // 30
+    assert _plan(d1080[7], 1, 32)["chunks"] == 64 // 30
+    # the channel split is a small-grid measure: on for a 256^2 image on the whole chip, off on a 32-CU partition; the K split is
+    # never automatic (measured a loss on this chip, sicn_plan.h) and takes IFM_CH / 64 slices when forced
+    d256 = eight_layer_descs(256, 256)
+    p = _plan(d256[2], 1, 256)
+    assert (p["family"], p["tile_x"], p["split_n"], p["split_k"], p["gy"], p["gz"]) == (1, 16, 2, 1, 2, 1)
+    assert (_plan(d256[3], 1, 256)["split_n"], _plan(d256[4], 1, 256)["split_n"]) == (3, 2)
+    p = _plan(d256[1], 1, 32)                           # 32 tiles on 32 CUs: no split
+    assert (p["split_n"], p["split_k"]) == (1, 1)
+    p = _plan(d256[3], 1, 256, split_k=2)
+    assert (p["split_n"], p["split_k"], p["gz"]) == (3, 2, 2)
+    p = _plan(d256[4], 1, 256, split_k=2)               # 192 input channels: three channel-group pairs
+    assert (p["split_n"], p["split_k"], p["gz"]) == (2, 3, 3)
+    assert _plan(d1080[2], 1, 256, split_n=2, split_k=2, tile_x=16)["split_k"] == 2      # forced on a full grid
+    # layer 0 runs: at most 9 tiles per workgroup, about four workgroups per CU on small images
+    p0 = _plan(d4k[0], 8, 256)
+    assert p0["ty_per"] <= 9 and p0["gy"] * p0["ty_per"] >= (1080 + 7) // 8
+    d768 = eight_layer_descs(768, 512)
+    assert _plan(d768[0], 1, 256)["gy"] == 32 and _plan(d768[0], 1, 32)["gy"] == 11

@@ -180,6 +180,97 @@ def test_output_channel_split_in_chain(api, split_n):
     assert _sha(latent[0].cpu().numpy()) == HASHES["layers"]["rng768"][3]
 
 
+def _run_layer_in_net(api, d, words, b, x_np, **options):
+    """One layer as a one-layer net chain (sicn_net_forward): the K split lives there, its scratch is part of the net's workspace."""
+    fpw = api.FixedPointWeights(d.SIMD, 4, d.PE, d.W_TILES, words)
+    net = api.EightLayersNet(descs=[d], params=[(fpw, b)], options=options or None)
+    out, _ = net.run_layers(0, 0, _dev(x_np))
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), net
+
+
+KSPLIT_CASES = MFMA_CASES + [(128, 128, 8, 16, 50, 20, 0), (192, 128, 12, 16, 37, 21, 1), (128, 192, 8, 24, 47, 18, 0),
+                             (192, 128, 12, 16, 45, 19, 0), (128, 192, 8, 24, 21, 13, 1), (128, 128, 8, 16, 33, 9, 1),
+                             (128, 128, 8, 16, 1, 1, 0), (192, 128, 12, 16, 1, 1, 1), (128, 192, 8, 24, 16, 8, 0)]
+
+
+@pytest.mark.parametrize("case", KSPLIT_CASES)
+def test_k_split_matches_oracle(api, case):
+    """K split (round 4): the channel-group pairs of a layer over 2 / 3 workgroups, every slice stores its
+    partial output bytes, the last one to arrive adds them mod 256 (exact: the reference's accumulator is ap_uint<8>,
+    mvau.hpp:112,160-170) and applies bias / ReLU — forced on EVERY MFMA shape, conv and deconv, batches, ragged edges, pixels
+    and activations >= 128, against the oracle."""
+    rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + 4242)
+    d = _mk_desc(*case)
+    W, b, words = _rand_params(rng, d)
+    x = rng.integers(0, 128, (3,) + d.in_shape, dtype=np.uint8)
+    x[1].reshape(-1)[::5] |= 0x80
+    got, net = _run_layer_in_net(api, d, words, b, x, tile_x=16, split_n=2, split_k=2)
+    plan = (ctypes.c_int32 * 12)()
+    from simple_image_compression_network_amd import _lib
+    o = _lib.make_options(tile_x=16, split_n=2, split_k=2)
+    assert _lib.lib().sicn_debug_plan(ctypes.byref(d.to_c()), 3, ctypes.byref(o), 256, plan) == 0
+    assert plan[6] == d.IFM_CH // 64 and plan[9] == plan[6]          # the K split really is what ran: IFM_CH / 64 slices
+    ref_fn = sicn_ref.deconv522_ref if d.transposed else sicn_ref.conv2d_ref
+    for i in range(3):
+        ref = ref_fn(x[i], W, b)
+        assert np.array_equal(got[i], ref), (i, np.count_nonzero(got[i] != ref))
+    # the unsplit kernel, same net shape: identical bytes
+    same, _ = _run_layer_in_net(api, d, words, b, x, tile_x=16, split_n=2, split_k=1)
+    assert np.array_equal(got, same)
+
+
+def test_k_split_scratch_needs_no_initialisation_and_cleans_up(api):
+    """The K-split arrival words live in the caller's workspace, which nobody initialises: whatever it holds — zeros, 0xFF,
+    random bytes, the leftovers of earlier launches — reads as "nobody has arrived" unless it carries the net's random 56-bit
+    tag, and the workgroup that finishes a tile clears its word.  Repeated calls, a captured graph replayed several times, and
+    poisoned scratch all give the same bytes."""
+    rng = np.random.default_rng(99)
+    d = _mk_desc(128, 192, 8, 24, 40, 24, 0)
+    W, b, words = _rand_params(rng, d)
+    x = rng.integers(0, 256, (2,) + d.in_shape, dtype=np.uint8)
+    ref = np.stack([sicn_ref.conv2d_ref(x[i], W, b) for i in range(2)])
+    fpw = api.FixedPointWeights(d.SIMD, 4, d.PE, d.W_TILES, words)
+    net = api.EightLayersNet(descs=[d], params=[(fpw, b)], options={"tile_x": 16, "split_n": 2, "split_k": 2})
+    xin = _dev(x)
+    ws = net.workspace(2)
+    for fill in ("zeros", "ones", "random", "leftover", "leftover"):
+        if fill == "zeros":
+            ws.zero_()
+        elif fill == "ones":
+            ws.fill_(0xFF)
+        elif fill == "random":
+            ws.copy_(torch.randint(0, 256, (ws.numel(),), dtype=torch.uint8, device="cuda"))
+        out, _ = net.run_layers(0, 0, xin)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), ref), fill
+    out = torch.zeros_like(out)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            net.run_layers(0, 0, xin, out=out)
+    for _ in range(4):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("size", [(768, 512, "rng768"), (256, 256, "rng256")])
+def test_k_split_in_chain(api, size):
+    """The whole net with the K split forced wherever the form exists (layers 1 - 6 at 8 x 16 tiles)."""
+    w, h, name = size
+    xin = _dev(_input(name)[None])
+    net = api.EightLayersNet(w, h, options={"tile_x": 16, "split_n": 2, "split_k": 2})
+    for _ in range(3):                      # the scratch is reused from layer to layer and from call to call
+        out, latent = net.forward(xin)
+        torch.cuda.synchronize()
+        assert _sha(out[0].cpu().numpy()) == HASHES["layers"][name][7]
+        assert _sha(latent[0].cpu().numpy()) == HASHES["layers"][name][3]
+
+
 PERSISTENT_CASES = [(128, 128, 8, 16, 130, 66, 0), (128, 128, 8, 16, 66, 18, 0), (128, 128, 8, 16, 7, 5, 0), (128, 128, 4, 32, 131, 33, 0),
                     (128, 128, 8, 16, 200, 90, 0), (128, 128, 8, 16, 64, 16, 0)]
 
