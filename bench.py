@@ -46,6 +46,7 @@ sys.path.insert(0, str(ROOT))
 
 PEAK_INT8_TOPS = 5000.0   # dense int8 MFMA = 2x the ~2.5 PFLOP/s bf16 dense peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0     # HBM3E spec
+NOMINAL_SCLK_MHZ = 2400.0  # the shader clock the nominal MFMA peak is quoted at
 KERNEL_SOURCES = ("k_common.hpp", "k_mfma16.hip", "k_mfma16p.hip", "k_mfma16x.hip", "k_mfma.hip", "k_rgb.hip", "k_generic.hip", "sicn_abi.hip")
 
 
@@ -55,6 +56,89 @@ def kernel_source_fingerprint() -> str:
     for name in KERNEL_SOURCES:
         h.update((ROOT / "simple_image_compression_network_amd" / "csrc" / name).read_bytes())
     return h.hexdigest()[:16]
+
+
+class ClockPowerSampler:
+    """Shader clock (MHz) and socket power (W) of one GPU, sampled by a side thread through amdsmi while a region runs — never
+    inside the stream (`roofline.frac` is against the nominal 5 POP/s = 2.4 GHz; this says what clock the
+    chip actually held, so a reader can split the gap into clock and issue without in-kernel stamps)."""
+
+    def __init__(self, pci_bus_id: str | None, period_s: float = 0.004):
+        self.period, self.h, self.err = period_s, None, None
+        self.regions, self._cur, self._stop, self._thr = {}, None, False, None
+        try:
+            import amdsmi
+            self.smi = amdsmi
+            amdsmi.amdsmi_init()
+            hs = amdsmi.amdsmi_get_processor_handles()
+            pick = None
+            for h in hs:
+                try:
+                    if pci_bus_id and amdsmi.amdsmi_get_gpu_device_bdf(h).lower() == pci_bus_id.lower():
+                        pick = h
+                except Exception:   # noqa: BLE001
+                    pass
+            self.h = pick if pick is not None else (hs[0] if len(hs) == 1 else None)
+            if self.h is None:
+                self.err = f"no amdsmi handle for {pci_bus_id} among {len(hs)}"
+        except Exception as e:   # noqa: BLE001
+            self.err = f"amdsmi unavailable: {type(e).__name__}: {e}"
+
+    def _read(self):
+        m = self.smi.amdsmi_get_gpu_metrics_info(self.h)
+        clks = [c for c in (m.get("current_gfxclks") or []) if isinstance(c, (int, float)) and 0 < c < 60000]
+        clk = sum(clks) / len(clks) if clks else m.get("current_gfxclk")
+        pw = m.get("current_socket_power")
+        if not isinstance(pw, (int, float)) or not 0 < pw < 60000:
+            pw = m.get("average_socket_power")
+        ok = lambda v: isinstance(v, (int, float)) and 0 < v < 60000
+        return (float(clk) if ok(clk) else None, float(pw) if ok(pw) else None)
+
+    def _loop(self):
+        import threading  # noqa: F401
+        while not self._stop:
+            name = self._cur
+            if name is not None:
+                try:
+                    self.regions.setdefault(name, []).append(self._read())
+                except Exception as e:   # noqa: BLE001
+                    self.err = f"{type(e).__name__}: {e}"
+                    return
+            time.sleep(self.period)
+
+    def start(self):
+        if self.h is None:
+            return self
+        import threading
+        self._thr = threading.Thread(target=self._loop, daemon=True)
+        self._thr.start()
+        return self
+
+    def region(self, name):
+        self._cur = name
+
+    def stop(self):
+        self._stop = True
+        if self._thr is not None:
+            self._thr.join(timeout=1.0)
+
+    def summary(self, name):
+        s = self.regions.get(name) or []
+        clk = [c for c, _ in s if c is not None]
+        pw = [p for _, p in s if p is not None]
+        return {"samples": len(s), "sclk_mhz_mean": round(sum(clk) / len(clk), 1) if clk else None,
+                "sclk_mhz_min": round(min(clk), 1) if clk else None, "sclk_mhz_max": round(max(clk), 1) if clk else None,
+                "power_w_mean": round(sum(pw) / len(pw), 1) if pw else None, "power_w_max": round(max(pw), 1) if pw else None}
+
+
+def device_identity(torch, dev) -> str:
+    """hostname + PCI address (+ uuid where torch exposes it) of a rank's GPU: what rank 0 gathers to prove that N DISTINCT
+    devices took part in an N-rank run."""
+    import socket
+    p = torch.cuda.get_device_properties(dev)
+    bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+    uuid = str(getattr(p, "uuid", "")) if hasattr(p, "uuid") else ""
+    return f"{socket.gethostname()}|{bdf}|{uuid}"
 
 
 def parse():
@@ -188,9 +272,10 @@ def small_configs(api, codec, dev):
                                   "bit_exact": sha(lat[0]) == want["latent_sha256"] and sha(rec[0]) == want["recon_sha256"],
                                   "workload": "BASELINE.json configs[2] without the coder: one 1920x1080 RGB image (seed 0), L0-L7, hipGraph replay"}
     lat2 = torch.empty_like(lat)
-    # the coder's stream length is an encoder parameter: 16384 = the format's default (96 streams for this latent: 96 waves on
-    # 256 CUs, each a serial chain of 256 steps); "auto" picks 4096 here (383 streams, a quarter of the chain, + 11 % bytes)
-    for key, ss in (("1080p_with_coder", None), ("1080p_with_coder_short_streams", "auto")):
+    # the coder's stream length is an encoder parameter: the default ("auto", codec.auto_stream_symbols) is 8192 for this latent
+    # (192 streams, + 2.8 % bytes over the format's 16384); 2048 (765 streams, an eighth of the chain, + 14 % bytes) is the
+    # explicit latency-over-rate choice
+    for key, ss in (("1080p_with_coder", "auto"), ("1080p_with_coder_short_streams", 2048)):
         coder = codec.LatentCoder(1, *net.descs[3].out_shape, image_width=W, image_height=H, device=dev, stream_symbols=ss)
 
         def coded():
@@ -240,6 +325,20 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    # which physical device is this rank on?  Gathered on every rank; an N-rank RCCL run on fewer than N distinct devices is refused
+    ident = device_identity(torch, dev)
+    rank_devices = [ident]
+    if use_dist:
+        buf = torch.zeros(160, dtype=torch.uint8, device=cdev)
+        raw = ident.encode()[:160]
+        buf[:len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
+        bufs = [torch.zeros_like(buf) for _ in range(world)]
+        dist.all_gather(bufs, buf)
+        rank_devices = [bytes(b.cpu().tolist()).rstrip(b"\0").decode() for b in bufs]
+        if args.backend == "nccl" and len(set(rank_devices)) != world:
+            raise SystemExit(f"rank {rank}: {world} ranks on {len(set(rank_devices))} distinct device(s): {rank_devices}")
+    sampler = ClockPowerSampler(ident.split("|")[1]).start() if rank == 0 else None
+
     W, H, B = args.width, args.height, args.images_per_gpu
     # synthetic inputs: uint8 NHWC, i.i.d. uniform 0..255, one seed per global image index
     host = np.stack([np.random.default_rng(rank * B + i).integers(0, 256, (H, W, 3), dtype=np.uint8) for i in range(B)])
@@ -261,49 +360,87 @@ def main():
     def step():
         net.forward(x, out, latent)
 
-    def timed(fn, steps):
-        """barrier + synchronize on both sides, MAX over ranks."""
+    class LegFailed(RuntimeError):
+        """some rank (not necessarily this one) failed inside a collective section of a secondary leg"""
+
+    def all_ok(ok: bool) -> bool:
+        """one MAX all-reduce of a failure flag: every rank learns at the SAME point whether any rank failed"""
+        if not use_dist:
+            return ok
+        f = torch.tensor([0 if ok else 1], dtype=torch.int32, device=cdev)
+        dist.all_reduce(f, op=dist.ReduceOp.MAX)
+        return int(f.item()) == 0
+
+    def guarded(fn):
+        """a section of a secondary leg WITHOUT collectives inside: its exception is held until every rank has reported, so
+        a failure on one rank only (out of memory, a coder check) never leaves the others blocked in the leg's next collective
+        (that used to be a hang, not an error)"""
+        err, res = None, None
+        try:
+            res = fn()
+        except Exception as e:   # noqa: BLE001
+            err = e
+        if not all_ok(err is None):
+            raise err if err is not None else LegFailed("another rank failed in this section")
+        return res
+
+    def timed(fn, steps, region=None):
+        """barrier + synchronize on both sides, MAX over ranks.  An exception inside the loop is held until the closing
+        collectives have run on every rank (they stay aligned), then raised everywhere."""
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+        if sampler is not None and region:
+            sampler.region(region)
+        err = None
         t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        torch.cuda.synchronize()
+        try:
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001
+            err = e
+        if sampler is not None and region:
+            sampler.region(None)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
         if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if not all_ok(err is None):
+            raise err if err is not None else LegFailed("another rank failed in the timed loop")
         return float(t.item())
 
+    secondary_errors = []
+
     def secondary(name, fn):
-        """A secondary measurement must never cost the headline line: an exception is reported in its place (and on stderr).
-        Every rank runs the same secondaries in the same order, so a failure that hits all ranks alike keeps the collectives
-        of `timed` aligned."""
+        """A secondary measurement must never cost the headline line: an exception is reported in its place, on stderr and in the
+        line's top-level `secondary_errors`.  Legs are built from `guarded` sections and `timed` loops, whose failures surface
+        on every rank at the same collective, so the ranks stay aligned and go on to the next leg together."""
         try:
             return fn()
         except Exception as e:   # noqa: BLE001 - reported, not swallowed
             import traceback
             traceback.print_exc(file=sys.stderr)
+            secondary_errors.append(name)
             return {"error": f"{name}: {type(e).__name__}: {e}"}
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    dt = timed(step, args.steps)          # the headline: nothing but the 8 launches per step on the stream
+    dt = timed(step, args.steps, "timed")   # the headline: nothing but the 8 launches per step on the stream
     # the per-layer table comes from a separate short loop (2 hipEvents per layer and step would sit inside `value` otherwise)
     net.profile(True)
     net.layer_ms(reset=True)
-    timed(step, max(10, min(args.steps, 40)))
+    timed(step, max(10, min(args.steps, 40)), "layers")
     layer_ms, launches = net.layer_ms(reset=True)
     net.profile(False)
     # a sustained region: the same step for >= 2 s (does the rate of the driver-sized region hold once the chip has settled?)
     sustained = None
     if not args.no_sustained:
         ssteps = max(args.steps, int(2.0 / (dt / args.steps)) + 1)
-        sdt = timed(step, ssteps)
+        sdt = timed(step, ssteps, "sustained")
         sustained = {"steps": ssteps, "seconds": round(sdt, 3), "ms_per_step": round(sdt / ssteps * 1e3, 3),
                      "value": round(world * B * W * H * ssteps / sdt / 1e6, 2), "unit": "Mpixels/s"}
 
@@ -331,7 +468,7 @@ def main():
     # ---- secondary: the same batch through the entropy coder ---------------------------------------
     def coder_leg():
         lat2 = torch.empty_like(latent)
-        coder = codec.LatentCoder(B, *net.descs[3].out_shape, image_width=W, image_height=H, device=dev)
+        coder = guarded(lambda: codec.LatentCoder(B, *net.descs[3].out_shape, image_width=W, image_height=H, device=dev))
 
         def coder_step():    # four enqueues, no host synchronisation anywhere inside
             net.analysis(x, latent)
@@ -339,11 +476,10 @@ def main():
             coder.decode(lat2)
             net.synthesis(lat2, out)
 
-        coder_step()
-        coder.check()
+        guarded(lambda: (coder_step(), coder.check()))
         csteps = max(2, args.steps // 2)
         cdt = timed(coder_step, csteps)
-        coder.check()        # device-side verdicts of the last step (checksums of the decoded latents included)
+        guarded(coder.check)   # device-side verdicts of the last step (checksums of the decoded latents included)
         ok = bool(torch.equal(lat2, latent)) and (zlib.adler32(out.cpu().numpy().reshape(-1)) & 0xFFFFFFFF) == rank_checksums[rank]
         return {"value": round(world * B * W * H * csteps / cdt / 1e6, 2), "unit": "Mpixels/s",
                       "ms_per_step": round(cdt / csteps * 1e3, 3), "steps": csteps,
@@ -357,18 +493,17 @@ def main():
     # ---- mode-3 coder for the hyper-latent, mode-4 conditional coder for the latent) on the same batch -----------------
     def hyper_leg():
         from simple_image_compression_network_amd.hyperprior import HyperpriorCodec
-        hc = HyperpriorCodec(W, H, B, seed=0, device=dev, main_params=params)
+        hc = guarded(lambda: HyperpriorCodec(W, H, B, seed=0, device=dev, main_params=params))
         out_h2 = torch.empty_like(out)
 
         def hyper_step():    # enqueue only: g_a, h_a, z coder, h_s, y coder | z decoder, h_s, y decoder, g_s
             hc.encode(x)
             hc.decode(out_h2)
 
-        hyper_step()
-        hc.check()
+        guarded(lambda: (hyper_step(), hc.check()))
         hsteps = max(2, args.steps // 4)
         hdt = timed(hyper_step, hsteps)
-        hc.check()
+        guarded(hc.check)
         direct = torch.empty_like(out)
         hc.main.forward(x, direct, want_latent=False)      # the same transform without the coders in between
         return {"value": round(world * B * W * H * hsteps / hdt / 1e6, 2), "unit": "Mpixels/s",
@@ -414,10 +549,15 @@ def main():
     # ---- secondaries of the multi-GPU runs (N > 1): strong scaling and the single-image band split ----------------------
     def strong_leg():
         per = max(1, 64 // world)                      # BASELINE.json configs[3]: 64 images in all, 64 / N per rank
-        xs = x[:per] if per <= B else torch.cat([x] * ((per + B - 1) // B))[:per]
-        outs_s = torch.empty((per,) + net.descs[-1].out_shape, dtype=torch.uint8, device=dev)
-        lat_s = torch.empty((per,) + net.descs[3].out_shape, dtype=torch.uint8, device=dev)
-        net.forward(xs, outs_s, lat_s)
+
+        def setup():
+            xs = x[:per] if per <= B else torch.cat([x] * ((per + B - 1) // B))[:per]
+            outs_s = torch.empty((per,) + net.descs[-1].out_shape, dtype=torch.uint8, device=dev)
+            lat_s = torch.empty((per,) + net.descs[3].out_shape, dtype=torch.uint8, device=dev)
+            net.forward(xs, outs_s, lat_s)
+            return xs, outs_s, lat_s
+
+        xs, outs_s, lat_s = guarded(setup)
         ssteps = max(4, args.steps // 2)
         sdt = timed(lambda: net.forward(xs, outs_s, lat_s), ssteps)
         return {"value": round(world * per * W * H * ssteps / sdt / 1e6, 2), "unit": "Mpixels/s", "scaling": "strong",
@@ -447,7 +587,11 @@ def main():
     strong = banded = None
     if (world > 1 or os.environ.get("SICN_BENCH_FORCE_DIST") == "1") and not args.headline_only:
         strong = secondary("strong_scaling", strong_leg)
+        # the band split has a data-path collective (the all-gather of the kept rows) INSIDE its step: a rank that fails there
+        # cannot be waited for; it runs last of the collective legs so that nothing else is lost with it
         banded = secondary("banded", banded_leg)
+    if sampler is not None:
+        sampler.stop()
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
@@ -491,6 +635,15 @@ def main():
     else:
         roof = {"bound": "hbm", "achieved": round(byts / (avg_ms[dom] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
                 "unit": "GB/s", "frac": round(byts / (avg_ms[dom] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+    # the clock and power the chip held while the per-layer table was measured (side-thread amdsmi samples): frac stays against the
+    # nominal peak; frac_at_clock = achieved / (peak x sclk / 2400 MHz) is the issue efficiency at the clock actually held
+    clk_l, clk_t = sampler.summary("layers"), sampler.summary("timed")
+    roof.update({"sclk_mhz_mean": clk_l["sclk_mhz_mean"], "power_w_mean": clk_l["power_w_mean"],
+                 "frac_at_clock": (round(roof["frac"] * NOMINAL_SCLK_MHZ / clk_l["sclk_mhz_mean"], 4)
+                                   if clk_l["sclk_mhz_mean"] and roof["bound"] == "mfma" else None),
+                 "clock_source": sampler.err or f"amdsmi gpu_metrics (mean of the XCDs' current_gfxclk, current_socket_power), "
+                                                f"{clk_l['samples']} samples at {int(sampler.period * 1e3)} ms over the per-layer loop; "
+                                                f"nominal peak assumes {NOMINAL_SCLK_MHZ} MHz"})
     roof.update({"traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": int(byts),
                  "kernel": f"layer {dom} ({names[dom]})", "avg_launch_ms": round(avg_ms[dom], 4),
                  "note": "int8 MAC = 2 ops, counted in the TFLOP/s unit; algorithmic (zero-skipped) work"})
@@ -505,6 +658,9 @@ def main():
         "output_bit_exact": (None if any(v < 0 for v in verdicts) and all(v != 0 for v in verdicts) else all(v == 1 for v in verdicts)),
         "output_check": "sha256 of every latent and reconstruction of the timed run vs tests/golden/bench_4k_hashes.json (oracle direct form)",
         "rank_checksums": rank_checksums,
+        "rank_devices": rank_devices, "distinct_devices": len(set(rank_devices)),
+        "world_size": (dist.get_world_size() if use_dist else 1),
+        "clocks": {"timed": clk_t, "layers": clk_l, "sustained": sampler.summary("sustained")},
         "roofline": roof, "layers": layers,
         "device_ms_sum_per_step": round(sum(avg_ms), 3),
         "whole_net_mfma_frac": round(net_ops / (dt / args.steps) / 1e12 / PEAK_INT8_TOPS, 4),
@@ -528,6 +684,7 @@ def main():
         res["hyperprior"] = hyper
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = secondary("cpu_baseline", lambda: cpu_baseline(host[0], args.cpu_sample, lat_h[0], out_h[0]))
+    res["secondary_errors"] = secondary_errors
     if use_dist:
         res["config"]["collectives"] = f"torch.distributed backend {dist.get_backend()} (bookkeeping only: weight broadcast, barrier, MAX of the timed region, checksum all-gather)"
     print(json.dumps(res))

@@ -47,12 +47,17 @@ extern "C" {
 #define SICN_CODEC_WSTREAM_SYMBOLS 16384 /* mode 3: 64 lanes x 256 steps */
 #define SICN_EBADMSG (-74) /* checksum of the decoded latent does not match the header */
 
+/* 44 bytes since library version 0.2 (sicn_version() >= 2): `stream_symbols` was appended in round 3 without a version bump
+ *  — a caller built against the 40-byte struct must check sicn_version() before passing it to sicn_codec_parse_header
+ * / sicn_codec_decode / sicn_codec_decode_batch, which write all 11 fields. */
 typedef struct sicn_codec_info {
     uint32_t mode, image_width, image_height, lat_w, lat_h, lat_c, n_symbols, n_streams, payload_bytes, adler32;
     uint32_t stream_symbols; /* header dword 9: symbols per stream (mode 3: the encoder's choice, see the _sl entry points) */
 } sicn_codec_info;
 
-/* Upper bound of the container size / device scratch needed for n_symbols latent bytes. */
+/* Upper bound of the container size / device scratch needed for n_symbols latent bytes.  sicn_codec_workspace_bytes(mode 3) covers
+ * a container of ANY admissible stream length (the decoders read the length from the header), sicn_codec_max_bytes(mode 3) the
+ * default length of 16384 (the _sl functions size a given length exactly). */
 size_t sicn_codec_max_bytes(int mode, uint32_t n_symbols);
 size_t sicn_codec_workspace_bytes(int mode, uint32_t n_symbols);
 
@@ -107,9 +112,11 @@ int sicn_codec_decode_batch_async(const uint8_t *containers, size_t slot_bytes, 
 /* The same pair with the STREAM LENGTH as an encoder parameter (mode 3 containers carry it in header dword 9, so every decoder
  * of this library — and the oracle — reads containers of any admissible length): stream_symbols = a power of two, 1024 ..
  * 16384 (SICN_CODEC_WSTREAM_SYMBOLS, what the entry points above use).  A stream is a serial chain of stream_symbols / 64
- * steps on one wave: a 1080p latent (1.57 M symbols) is 96 streams of 16384 — 96 waves on 256 CUs, ≈ 50 / 62 us to encode /
- * decode — or 383 streams of 4096 at a quarter of that; each extra stream costs 260 bytes (its 64 final states and its length
- * entry: + 11 % bytes at 4096 on that latent, + 3 % at 8192).  Large batches (8 x 4K: 3040 streams of 16384) gain nothing.
+ * steps on one wave: a 1080p latent (1.57 M symbols) is 96 streams of 16384 — 96 waves on 256 CUs — or 192 of 8192 at half
+ * the chain, 765 of 2048 at an eighth; every stream ends with 260 bytes of flush (its 64 final states and its length entry), which
+ * is inherent to 64 interleaved states (>= 16 bits each): + 2.8 % bytes at 8192 on that latent, + 8 % at 4096, + 14 % at 2048
+ * (measured r03: 3.45 -> 3.94 bit / pixel).  The Python wrapper's default (codec.auto_stream_symbols) is 16384 for latents of at
+ * least 128 such streams and 8192 below — a function of ONE image's latent, never of the batch.  Large batches gain nothing.
  * Size the slots and the workspace with the _sl functions; the decoder must be given the same length (a container whose
  * header disagrees is an error, bit 2). */
 size_t sicn_codec_max_bytes_sl(uint32_t n_symbols, uint32_t stream_symbols);

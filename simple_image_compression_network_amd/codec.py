@@ -17,13 +17,16 @@ WSTREAM_SYMBOLS = 16384   # SICN_CODEC_WSTREAM_SYMBOLS: the default (and longest
 
 
 def auto_stream_symbols(n_symbols: int, n_images: int = 1) -> int:
-    """The longest admissible stream (best compression) that still gives the chip about two waves per CU: a stream is a serial
-    chain on ONE wave, so a small latent coded in few long streams leaves the GPU idle for the length of that chain.
-    8 x 4K latents: 16384 (3040 streams); one 1080p latent: 4096 (383 streams, + 11 % bytes, a quarter of the latency)."""
-    for ss in (16384, 8192, 4096, 2048):
-        if -(-n_symbols // ss) * n_images >= 512:
-            return ss
-    return 2048 if n_symbols * n_images >= 2048 * 64 else 1024
+    """Stream length of the rANS-W coder as a function of ONE image's latent only (`n_images` is accepted and ignored: the
+    bitstream of an image must not depend on how many images were coded beside it — ADVICE r3; a container written by a batch of
+    8 decodes in a batch of 1).  A stream is a serial chain on one wave and ends with 260 bytes of flush (its 64 final states and
+    its length entry), so the choice trades latency against bytes:
+      * 16384 (the format's default, 2.8 % flush at 4.5 bit / symbol) for latents of at least 128 such streams — a 4K image's
+        6.2 M symbols are 380;
+      * 8192 otherwise (one 1080p latent: 192 streams, half the chain, + 2.8 % bytes: 3.54 instead of 3.45 bit / pixel).
+    Shorter streams remain an explicit choice (`stream_symbols=2048`: a quarter of that chain again, + 14 % bytes)."""
+    del n_images
+    return 16384 if n_symbols >= 128 * 16384 else 8192
 
 
 def _stream_ptr(stream):
@@ -118,16 +121,15 @@ class LatentCoder:
 
     def __init__(self, n_images: int, lat_h: int, lat_w: int, lat_c: int, image_width: int = 0, image_height: int = 0,
                  device="cuda", stream_symbols=None):
-        """stream_symbols: None = 16384 (the format's default), "auto" = `auto_stream_symbols`, or a power of two 1024 .. 16384
-        (sicn_codec_*_async_sl: shorter streams = shorter critical path on small latents, 260 bytes per extra stream).  A
-        decoder object must be built with the encoder's value."""
+        """stream_symbols: None or "auto" = `auto_stream_symbols` of ONE image's latent (16384 for large latents, 8192 below 2 M
+        symbols), or a power of two 1024 .. 16384 (sicn_codec_*_async_sl: shorter streams = shorter critical path on small latents,
+        260 bytes per extra stream).  A decoder object must be built with the encoder's value (the container header carries it)."""
         import torch
         L = _lib.lib()
         self.shape = (int(n_images), int(lat_h), int(lat_w), int(lat_c))
         self.image_wh = (int(image_width), int(image_height))
         n = lat_h * lat_w * lat_c
-        self.stream_symbols = (WSTREAM_SYMBOLS if stream_symbols is None else
-                               auto_stream_symbols(n, n_images) if stream_symbols == "auto" else int(stream_symbols))
+        self.stream_symbols = auto_stream_symbols(n) if stream_symbols in (None, "auto") else int(stream_symbols)
         if self.stream_symbols not in (1024, 2048, 4096, 8192, 16384):
             raise ValueError("stream_symbols must be a power of two in 1024 .. 16384")
         self.slot = (int(L.sicn_codec_max_bytes_sl(n, self.stream_symbols)) + 255) // 256 * 256

@@ -21,6 +21,7 @@
 
 #include "../../include/sicn.h"
 #include "../../include/sicn_codec.h"
+#include "sicn_internal.h"   // chip_geom(): how many waves the device holds decides between the decoder's two table forms
 
 namespace {
 
@@ -236,26 +237,172 @@ __device__ __forceinline__ void ransw_build(RanswTab &t, const uint16_t *freq, i
 constexpr uint32_t RING_WORDS = 4096;
 __device__ __forceinline__ void ring_flush(const uint16_t *ring, uint16_t *dst, uint32_t gpos, uint32_t top, uint32_t lane)
 {
-    for (uint32_t i = gpos + lane; i < top; i += 64) dst[i] = ring[i & (RING_WORDS - 1)];
+    // word i of the stream sits at ring[i % RING_WORDS] and goes to dst[i]: 8-word groups at multiples of 8 are contiguous and
+    // 16-byte aligned on both sides (RING_WORDS % 8 == 0, dst is a scratch slot at a 16-byte multiple), so the body moves 16 bytes
+    // per lane and instruction; the ragged head and tail go word by word (round 4: the whole run used to go 2 bytes at a time)
+    const bool vec = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+    const uint32_t a = vec ? min(top, (gpos + 7u) & ~7u) : top, b = vec ? max(a, top & ~7u) : top;
+    for (uint32_t i = gpos + lane; i < a; i += 64) dst[i] = ring[i & (RING_WORDS - 1)];
+    for (uint32_t i = a + 8 * lane; i < b; i += 8 * 64)
+        *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(ring + (i & (RING_WORDS - 1)));
+    for (uint32_t i = b + lane; i < top; i += 64) dst[i] = ring[i & (RING_WORDS - 1)];
 }
 __device__ __forceinline__ uint32_t ring_fill(uint16_t *ring, const uint16_t *src, uint32_t loaded, uint32_t upto, uint32_t lane)
 {
+    // the payload side is only 2-byte aligned (streams start at even container offsets): dwords when the source happens to be
+    // 4-byte aligned relative to the ring's even word indices, else word by word
+    if ((reinterpret_cast<uintptr_t>(src) & 3) == 0) {
+        const uint32_t a = min(upto, (loaded + 1u) & ~1u), b = max(a, upto & ~1u);
+        if (lane == 0 && loaded < a) ring[loaded & (RING_WORDS - 1)] = src[loaded];
+        for (uint32_t i = a + 2 * lane; i < b; i += 128)
+            *reinterpret_cast<uint32_t *>(ring + (i & (RING_WORDS - 1))) = *reinterpret_cast<const uint32_t *>(src + i);
+        if (lane == 0 && b < upto) ring[b & (RING_WORDS - 1)] = src[b];
+        return upto;
+    }
     for (uint32_t i = loaded + lane; i < upto; i += 64) ring[i & (RING_WORDS - 1)] = src[i];
     return upto;
 }
 
+// ---- the encoder's per-symbol table: one 16-byte entry (ONE ds_read_b128) instead of two dword tables, and the renormalisation
+// ---- test as a precomputed threshold.  Round 4: the step loop used to make two dependent LDS round trips per symbol (frequency,
+// ---- then reciprocal, each behind an s_waitcnt and a branch); now the four entries of a block are fetched while the PREVIOUS
+// ---- block's chain runs and the step itself is branch-free.
+struct RanswEnt {
+    uint32_t fc;    // freq | cum << 16
+    uint32_t rcp;   // ransw_rcp(freq)
+    uint32_t thr;   // a lane renormalises iff x > thr: freq * 2^20 - 1 (freq = 4096: never, 2^32 - 1; freq = 0: unused symbol)
+    uint32_t pad;
+};
+__device__ __forceinline__ RanswEnt ransw_ent(uint32_t f, uint32_t c)
+{
+    return RanswEnt{f | (c << 16), ransw_rcp(f), (f == 0 || f >= 4096u) ? 0xFFFFFFFFu : (f << 20) - 1u, 0u};
+}
+// table of one wave from this lane's two frequencies (symbols 2 lane, 2 lane + 1): exclusive prefix sum by a wavefront scan
+__device__ __forceinline__ void ransw_build_ent(RanswEnt *ent, uint32_t f0, uint32_t f1, int lane)
+{
+    uint32_t incl = f0 + f1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    const uint32_t c0 = incl - f0 - f1;
+    ent[2 * lane] = ransw_ent(f0, c0);
+    ent[2 * lane + 1] = ransw_ent(f1, c0 + f0);
+}
+
+// Histogram -> 12-bit frequencies exactly as `normalize` / sicl_or_normalize do it (same floor, same "largest first, lowest index
+// on ties" correction walk), by ONE wave: lane l owns symbols 2l, 2l+1 (hh = their counts).  Returns the error bits (2 = no valid table).
+__device__ __forceinline__ uint32_t normalize_wave(const uint32_t (&hh)[2], uint32_t n, uint32_t (&f)[2], int lane)
+{
+    uint32_t err = 0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const uint32_t h = hh[k];
+        unsigned long long v = (h && n) ? ((unsigned long long)h * 4096u) / n : 0;
+        if (h && v == 0) v = 1;
+        f[k] = (uint32_t)v;
+    }
+    int sum = (int)(f[0] + f[1]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+    int diff = n ? 4096 - sum : 0;
+    for (int it = 0; it < 200 && diff != 0; it++) {
+        // candidate of this lane: f > 0 and (diff > 0 or f > 1); key = (f << 8) | (255 - index): max key = largest f, lowest index
+        uint32_t key = 0;
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            if (f[k] > 0 && (diff > 0 || f[k] > 1)) key = max(key, (f[k] << 8) | (uint32_t)(255 - (2 * lane + k)));
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) key = max(key, (uint32_t)__shfl_xor((int)key, d));
+        if (key == 0) { err |= 2; break; }
+        const int best = 255 - (int)(key & 255u), fb = (int)(key >> 8);
+        const int step = diff > 0 ? diff : (diff < 1 - fb ? 1 - fb : diff);
+        if ((best >> 1) == lane) f[best & 1] = (uint32_t)(fb + step);
+        diff -= step;
+    }
+    if (diff != 0) err |= 2;
+    return err;
+}
+
+// container header (dwords 0..11 but 10 = payload bytes, written by the scan / compaction stage) + frequency table, by one wave
+__device__ __forceinline__ void write_header_wave(uint8_t *out, const uint32_t (&f)[2], unsigned long long s1, unsigned long long s2,
+                                                  uint32_t n, uint32_t ns, uint32_t lat_w, uint32_t lat_h, uint32_t lat_c, uint32_t img_w,
+                                                  uint32_t img_h, uint32_t wss, int lane)
+{
+    uint8_t *ft = out + SICN_CODEC_HEADER_BYTES + 4 * lane;
+    ft[0] = (uint8_t)f[0]; ft[1] = (uint8_t)(f[0] >> 8); ft[2] = (uint8_t)f[1]; ft[3] = (uint8_t)(f[1] >> 8);
+    if (lane < 12) {
+        const uint32_t a = (uint32_t)((1 + s1) % ADLER_MOD), b = (uint32_t)((n % ADLER_MOD + s2) % ADLER_MOD);
+        const uint32_t words[12] = {0x4C434953u /* "SICL" */, 1u | ((uint32_t)SICN_CODEC_RANSW << 16), img_w, img_h, lat_w, lat_h,
+                                    lat_c, n, ns, wss, 0u, (b << 16) | a};
+        if (lane != 10) {
+            const uint32_t v = words[lane];
+            uint8_t *p = out + 4 * lane;
+            p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
+        }
+    }
+}
+
+// what the asynchronous encoder's streams need to make the frequency table THEMSELVES from the statistics rows (row mode:
+// one launch less — the header kernel was 8.5 us of a 1080p encode, nearly all of it launch latency): every wave sums the rows
+// and runs the (deterministic) normalisation; stream 0's wave also writes header, table and status
+struct EncSelfHeader {
+    const uint32_t *rows;     // [n_rows][STAT_ROW_WORDS] per image (stride s_ws), or nullptr: the table comes from freq_g
+    uint32_t n_rows;
+    uint8_t *out;             // containers (stride s_slot)
+    size_t s_slot;
+    uint32_t *status;         // sicn_codec_status[n_images]
+    uint32_t lat_w, lat_h, lat_c, img_w, img_h;
+};
+
 __global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__ lat_, uint32_t n, uint32_t ns,
                                                      const uint16_t *__restrict__ freq_g_, uint8_t *__restrict__ scratch_,
-                                                     uint32_t *__restrict__ lens_, size_t s_lat, size_t s_ws, uint32_t wss)
+                                                     uint32_t *__restrict__ lens_, size_t s_lat, size_t s_ws, uint32_t wss,
+                                                     EncSelfHeader sh = EncSelfHeader{})
 {
     const uint8_t *lat = img_ptr(lat_, s_lat);
-    const uint16_t *freq_g = img_ptr(freq_g_, s_ws);
     uint8_t *scratch = img_ptr(scratch_, s_ws);
     uint32_t *lens = img_ptr(lens_, s_ws);
-    __shared__ RanswTab tab;
+    __shared__ __attribute__((aligned(16))) RanswEnt ent[128];
     __shared__ __attribute__((aligned(16))) uint16_t words[RING_WORDS];
     const uint32_t st = blockIdx.x, lane = threadIdx.x;
-    ransw_build(tab, freq_g, (int)lane);
+    if (sh.rows) {
+        const uint32_t *rows = img_ptr(sh.rows, s_ws);
+        uint32_t hh[2] = {0, 0}, hi = 0;
+#pragma unroll 8
+        for (uint32_t r = 0; r < sh.n_rows; r++) {
+            const uint32_t *row = rows + (size_t)r * STAT_ROW_WORDS;
+            const uint2 two = *reinterpret_cast<const uint2 *>(row + 2 * lane);
+            hh[0] += two.x;
+            hh[1] += two.y;
+            hi |= row[128 + lane] | row[192 + lane];
+        }
+        uint32_t f[2];
+        uint32_t err = normalize_wave(hh, n, f, (int)lane) | (hi ? 1u : 0u);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) err |= (uint32_t)__shfl_xor((int)err, d);
+        if (err) f[0] = f[1] = 0;   // zero-frequency symbols are skipped below: the kernel stays memory-safe
+        ransw_build_ent(ent, f[0], f[1], (int)lane);
+        if (st == 0) {              // header, table and encoder status of this image: once
+            unsigned long long s1 = 0, s2 = 0;
+            for (uint32_t r = lane; r < sh.n_rows; r += 64) {
+                const unsigned long long *q = (const unsigned long long *)(rows + (size_t)r * STAT_ROW_WORDS + 256);
+                s1 += q[0];
+                s2 += q[1];
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                s1 += __shfl_xor(s1, d);
+                s2 += __shfl_xor(s2, d);
+            }
+            write_header_wave(img_ptr(sh.out, sh.s_slot), f, s1, s2, n, ns, sh.lat_w, sh.lat_h, sh.lat_c, sh.img_w, sh.img_h, wss, (int)lane);
+            if (lane == 0) sh.status[2 * blockIdx.y] = err;
+        }
+    } else {
+        const uint16_t *freq_g = img_ptr(freq_g_, s_ws);
+        ransw_build_ent(ent, freq_g[2 * lane], freq_g[2 * lane + 1], (int)lane);
+    }
     __syncthreads();
     const uint32_t wcap = wstream_cap(wss);
     const uint32_t begin = st * wss, cnt = min(wss, n - begin), blocks = (cnt + 255) / 256;
@@ -272,32 +419,41 @@ __global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__
             if (j + k < cnt) v |= (uint32_t)lat[begin + j + k] << (8 * k);
         return v;
     };
-    uint32_t nxt = blocks ? load4(blocks - 1) : 0;
+    const uint4 *ent4 = reinterpret_cast<const uint4 *>(ent);
+    // software pipeline, two blocks deep: symbols of block q - 2 in flight from memory, table entries of block q - 1 in flight from
+    // LDS, block q's chain on registers (symbols >= 128 are an error the statistics stage flags; they are masked here)
+    uint32_t s_next = blocks > 1 ? load4(blocks - 2) : 0;
+    uint4 e_cur[4];
+    {
+        const uint32_t s_cur = blocks ? load4(blocks - 1) : 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) e_cur[k] = ent4[(s_cur >> (8 * k)) & 127u];
+    }
     for (uint32_t q = blocks; q-- > 0;) {
-        const uint32_t sym4 = nxt;
-        if (q) nxt = load4(q - 1);   // the next block's symbols are in flight while this one is coded
+        const uint32_t s_next2 = q >= 2 ? load4(q - 2) : 0;
+        uint4 e_next[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) e_next[k] = ent4[(s_next >> (8 * k)) & 127u];
+        const int have = (int)min(4u, cnt - min(cnt, q * 256 + lane * 4));   // symbols of this lane in this block (4 but in a short last one)
 #pragma unroll
         for (int k = 3; k >= 0; k--) {
-            const bool active0 = q * 256 + lane * 4 + k < cnt;
-            const uint32_t sy = (sym4 >> (8 * k)) & 127u;   // symbols >= 128 are an error flagged by the statistics stage
-            const uint32_t t = tab.fc[sy];
-            const uint32_t c = t >> 16;
-            uint32_t f = t & 0xFFFFu;
-            const bool active = active0 && f != 0;          // f == 0 only for a latent the header stage rejected
-            f = active ? f : 1u;
-            const bool emit = active && (unsigned long long)x >= ((unsigned long long)f << 20);
+            const uint32_t f = e_cur[k].x & 0xFFFFu, c = e_cur[k].x >> 16;
+            const bool active = k < have && f != 0;          // f == 0 only for a latent the header stage rejected
+            const bool emit = active && x > e_cur[k].z;      // x >= f * 2^20
             const unsigned long long mask = __ballot(emit);
             pos -= (uint32_t)__popcll(mask);
-            if (emit) {
-                words[(pos + (uint32_t)__popcll(mask & below)) & (RING_WORDS - 1)] = (uint16_t)x;   // ascending lane order inside the step
-                x >>= 16;
-            }
-            if (active) {
-                uint32_t r;
-                const uint32_t qq = ransw_div(x, f, tab.rcp[sy], r);
-                x = (qq << PROB_BITS) + r + c;
-            }
+            if (emit) words[(pos + (uint32_t)__popcll(mask & below)) & (RING_WORDS - 1)] = (uint16_t)x;   // ascending lane order inside the step
+            x = emit ? x >> 16 : x;
+            uint32_t qq = __umulhi(x, e_cur[k].y);           // floor(x / f) or one less (ransw_div)
+            uint32_t r = x - qq * f;
+            const bool fix = r >= f;
+            qq += fix ? 1u : 0u;
+            r -= fix ? f : 0u;
+            x = active ? (qq << PROB_BITS) + r + c : x;
         }
+#pragma unroll
+        for (int k = 0; k < 4; k++) e_cur[k] = e_next[k];
+        s_next = s_next2;
         if (top - pos > RING_WORDS - 4 * 64 - 128) {   // the next 4 steps (and the final states) must still fit
             __syncthreads();
             ring_flush(words, dst, pos, top, lane);
@@ -313,6 +469,11 @@ __global__ __launch_bounds__(64) void k_ransw_encode(const uint8_t *__restrict__
     if (lane == 0) lens[st] = (wcap / 2 - pos) * 2;
 }
 
+// BIGTAB (the latency form, taken when an image's streams are few enough that occupancy does not matter): ONE 4096-entry dword
+// table v -> symbol | freq << 7 | (v - cum) << 20 instead of the byte table v -> symbol followed by the symbol's (freq, cum): a
+// decode step's chain is table -> multiply-add -> renormalisation word, and the second dependent LDS round trip is gone.  16 KB of
+// LDS more per wave (5 waves per CU instead of 12), so large batches keep the two-table form, whose latency the other waves hide.
+template <bool BIGTAB>
 __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__ payload_, const uint8_t *__restrict__ freq_bytes_,
                                                      const uint32_t *__restrict__ offsets_, uint32_t n, uint32_t ns,
                                                      uint8_t *__restrict__ lat_, uint32_t *__restrict__ err_, size_t s_slot,
@@ -355,6 +516,7 @@ __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__
     __shared__ uint16_t freq[128];
     __shared__ __attribute__((aligned(16))) uint8_t slot[4096];
     __shared__ __attribute__((aligned(16))) uint16_t words[RING_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t big[BIGTAB ? 4096 : 4];
     freq[2 * lane] = (uint16_t)(freq_bytes[4 * lane] | (freq_bytes[4 * lane + 1] << 8));
     freq[2 * lane + 1] = (uint16_t)(freq_bytes[4 * lane + 2] | (freq_bytes[4 * lane + 3] << 8));
     __syncthreads();
@@ -368,6 +530,21 @@ __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__
         const uint32_t pat = sy * 0x01010101u;
         for (; v + 16 <= e; v += 16) *reinterpret_cast<uint4 *>(slot + v) = make_uint4(pat, pat, pat, pat);
         for (; v < e; v++) slot[v] = (uint8_t)sy;
+    }
+    if constexpr (BIGTAB) {   // expand: entry v = symbol | freq << 7 | (v - cum) << 20 (7 + 13 + 12 bits), four consecutive v per lane and round
+        __syncthreads();
+#pragma unroll 4
+        for (uint32_t v0 = 4 * lane; v0 < 4096; v0 += 256) {
+            const uint32_t s4 = *reinterpret_cast<const uint32_t *>(slot + v0);
+            uint4 o;
+            uint32_t *ov = reinterpret_cast<uint32_t *>(&o);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t sy = (s4 >> (8 * k)) & 255u, t = tab.fc[sy & 127u];
+                ov[k] = sy | ((t & 0xFFFFu) << 7) | ((v0 + k - (t >> 16)) << 20);
+            }
+            *reinterpret_cast<uint4 *>(big + v0) = o;
+        }
     }
     const uint32_t begin = st * wss, cnt = min(wss, n - begin), blocks = (cnt + 255) / 256;
     uint32_t off, len;
@@ -423,25 +600,32 @@ __global__ __launch_bounds__(64) void k_ransw_decode(const uint8_t *__restrict__
             __syncthreads();
         }
         uint32_t out4 = 0;
+        const int have = (int)min(4u, cnt - min(cnt, q * 256 + lane * 4));   // symbols of this lane in this block
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const bool active = q * 256 + lane * 4 + k < cnt;
-            if (active) {
-                const uint32_t v = x & 4095u, sy = slot[v], t = tab.fc[sy];
-                out4 |= sy << (8 * k);
-                x = (t & 0xFFFFu) * (x >> PROB_BITS) + v - (t >> 16);
-                s1 += sy;
-                s2 += (unsigned long long)(n - (begin + q * 256 + lane * 4 + k)) * sy;   // < 2^38 per term, 1024 terms per lane
+            const bool active = k < have;
+            uint32_t sy, xn;
+            if constexpr (BIGTAB) {
+                const uint32_t e = big[x & 4095u];
+                sy = e & 127u;
+                xn = ((e >> 7) & 0x1FFFu) * (x >> PROB_BITS) + (e >> 20);
+            } else {
+                const uint32_t v = x & 4095u;
+                sy = slot[v];
+                const uint32_t t = tab.fc[sy];
+                xn = (t & 0xFFFFu) * (x >> PROB_BITS) + v - (t >> 16);
             }
+            sy = active ? sy : 0u;
+            x = active ? xn : x;
+            out4 |= sy << (8 * k);
+            s1 += sy;
+            s2 += (unsigned long long)(n - (begin + q * 256 + lane * 4 + k)) * sy;   // < 2^38 per term, 1024 terms per lane (sy = 0 when inactive)
             const bool need = active && x < RANSW_L;
             const unsigned long long mask = __ballot(need);
-            if (need) {
-                const uint32_t idx = wpos + (uint32_t)__popcll(mask & below);
-                if (idx < loaded)        // loaded <= nwords; a stream that runs dry is malformed
-                    x = (x << 16) | words[idx & (RING_WORDS - 1)];
-                else
-                    bad = true;
-            }
+            const uint32_t idx = wpos + (uint32_t)__popcll(mask & below);
+            const uint32_t wd = words[idx & (RING_WORDS - 1)];   // read unconditionally: no branch on the chain
+            bad = bad || (need && idx >= loaded);                // loaded <= nwords; a stream that runs dry is malformed
+            x = (need && idx < loaded) ? (x << 16) | wd : x;
             wpos += (uint32_t)__popcll(mask);
         }
         const uint32_t j = q * 256 + lane * 4;
@@ -615,7 +799,13 @@ __global__ __launch_bounds__(256) void k_compact_self(const uint8_t *__restrict_
     const uint32_t off = part[0] + part[1] + part[2] + part[3];
     const uint8_t *src = scratch + (size_t)st * cap + (cap - len);
     uint8_t *dst = payload + off;
-    for (uint32_t i = threadIdx.x; i < len; i += 256) dst[i] = src[i];
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 1) == 0) {   // lengths and offsets are even: 2 bytes at least
+        const uint16_t *s2 = reinterpret_cast<const uint16_t *>(src);
+        uint16_t *d2 = reinterpret_cast<uint16_t *>(dst);
+        for (uint32_t i = threadIdx.x; i < len / 2; i += 256) d2[i] = s2[i];
+        if ((len & 1) && threadIdx.x == 0) dst[len - 1] = src[len - 1];
+    } else
+        for (uint32_t i = threadIdx.x; i < len; i += 256) dst[i] = src[i];
     if (threadIdx.x == 0) {
         uint8_t *p = table + 4 * (size_t)st;
         p[0] = (uint8_t)len; p[1] = (uint8_t)(len >> 8); p[2] = (uint8_t)(len >> 16); p[3] = (uint8_t)(len >> 24);
@@ -764,49 +954,13 @@ __global__ __launch_bounds__(256) void k_enc_header(const uint32_t *__restrict__
     }
     if (hi) err = 1;
     uint32_t f[2];
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const uint32_t h = hh[k];
-        unsigned long long v = (h && n) ? ((unsigned long long)h * 4096u) / n : 0;
-        if (h && v == 0) v = 1;
-        f[k] = (uint32_t)v;
-    }
-    int sum = (int)(f[0] + f[1]);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
-    int diff = n ? 4096 - sum : 0;
-    for (int it = 0; it < 200 && diff != 0; it++) {
-        // candidate of this lane: f > 0 and (diff > 0 or f > 1); key = (f << 8) | (255 - index): max key = largest f, lowest index
-        uint32_t key = 0;
-#pragma unroll
-        for (int k = 0; k < 2; k++)
-            if (f[k] > 0 && (diff > 0 || f[k] > 1)) key = max(key, (f[k] << 8) | (uint32_t)(255 - (2 * lane + k)));
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) key = max(key, (uint32_t)__shfl_xor((int)key, d));
-        if (key == 0) { err |= 2; break; }
-        const int best = 255 - (int)(key & 255u), fb = (int)(key >> 8);
-        const int step = diff > 0 ? diff : (diff < 1 - fb ? 1 - fb : diff);
-        if ((best >> 1) == lane) f[best & 1] = (uint32_t)(fb + step);
-        diff -= step;
-    }
-    if (diff != 0) err |= 2;
+    err |= normalize_wave(hh, n, f, lane);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) err |= (uint32_t)__shfl_xor((int)err, d);
     if (err) f[0] = f[1] = 0;   // the encode kernel skips zero-frequency symbols: it stays memory-safe
     freq[2 * lane] = (uint16_t)f[0];
     freq[2 * lane + 1] = (uint16_t)f[1];
-    uint8_t *ft = out + SICN_CODEC_HEADER_BYTES + 4 * lane;
-    ft[0] = (uint8_t)f[0]; ft[1] = (uint8_t)(f[0] >> 8); ft[2] = (uint8_t)f[1]; ft[3] = (uint8_t)(f[1] >> 8);
-    if (lane < 12) {   // header dwords 0..11 (dword 10 = payload bytes is written by k_scan / k_compact_self)
-        const uint32_t a = (uint32_t)((1 + s1) % ADLER_MOD), b = (uint32_t)((n % ADLER_MOD + s2) % ADLER_MOD);
-        const uint32_t words[12] = {0x4C434953u /* "SICL" */, 1u | ((uint32_t)SICN_CODEC_RANSW << 16), img_w, img_h, lat_w, lat_h,
-                                    lat_c, n, ns, wss, 0u, (b << 16) | a};
-        if (lane != 10) {
-            const uint32_t v = words[lane];
-            uint8_t *p = out + 4 * lane;
-            p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
-        }
-    }
+    write_header_wave(out, f, s1, s2, n, ns, lat_w, lat_h, lat_c, img_w, img_h, wss, lane);
     if (lane == 0) status[0] = err;
 }
 
@@ -1057,6 +1211,12 @@ extern "C" size_t sicn_codec_max_bytes(int mode, uint32_t n)
 extern "C" size_t sicn_codec_workspace_bytes(int mode, uint32_t n)
 {
     Workspace w;
+    if (mode == SICN_CODEC_RANSW) {   // enough for a container of ANY admissible stream length (sicn_codec_decode reads it from the header)
+        size_t mx = 0;
+        for (uint32_t wss = 1024; wss <= WSS; wss <<= 1)
+            if (wstream_fits(n, wss)) mx = std::max(mx, carve(w, nullptr, (n + wss - 1) / wss, wstream_cap(wss)) + 64);
+        return mx;
+    }
     const uint32_t ns = (n + stream_symbols(mode) - 1) / stream_symbols(mode);
     return carve(w, nullptr, ns, mode >= SICN_CODEC_RANS ? stream_cap(mode) : 0) + 64;
 }
@@ -1231,7 +1391,7 @@ extern "C" int sicn_codec_decode(const uint8_t *container, size_t bytes, uint8_t
         HIP_TRY(hipStreamSynchronize(stream));
         if (total != info.payload_bytes) return SICN_EINVAL;
         if (ns && info.mode == SICN_CODEC_RANSW)
-            hipLaunchKernelGGL(k_ransw_decode, dim3(ns), dim3(64), 0, stream, payload, freq_bytes, w.offsets, n, ns, latent, err, (size_t)0, (size_t)0, (size_t)0,
+            hipLaunchKernelGGL(k_ransw_decode<false>, dim3(ns), dim3(64), 0, stream, payload, freq_bytes, w.offsets, n, ns, latent, err, (size_t)0, (size_t)0, (size_t)0,
                                container + 40, (const uint32_t *)nullptr, (unsigned long long *)nullptr, info.stream_symbols);
         else if (ns)
             hipLaunchKernelGGL(k_rans_decode, dim3((ns + 255) / 256), dim3(256), 0, stream, payload, freq_bytes, w.offsets, n, ns, latent, err,
@@ -1283,13 +1443,14 @@ extern "C" int sicn_codec_encode_batch_async_sl(const uint8_t *latents, uint32_t
     uint8_t *table = out + SICN_CODEC_HEADER_BYTES + 256, *payload = table + 4 * (size_t)ns;
     const uint32_t fixed = (uint32_t)(SICN_CODEC_HEADER_BYTES + 256 + 4 * (size_t)ns);
     if (ns && ns <= SELF_SCAN_MAX) {
-        // four launches: statistics in rows (no clear, no atomics) -> header + table -> streams -> compaction with its own scan
+        // three launches (round 4; four in round 3, six in round 2): statistics in rows (no clear, no atomics) -> streams, every
+        // wave making the frequency table from the rows itself and stream 0's wave writing header, table and status ->
+        // compaction with its own scan
         const uint32_t n_rows = std::min(std::max(n / 16384u, 1u), STAT_ROWS);
         hipLaunchKernelGGL(k_stats, dim3(n_rows, n_images), dim3(256), 0, stream, latents, n, w.hist, w.sums, (size_t)n, ws1, w.rows);
-        hipLaunchKernelGGL(k_enc_header, dim3(1, n_images), dim3(256), 0, stream, w.hist, w.sums, w.freq, out, status, n, ns, lat_w,
-                           lat_h, lat_c, img_w, img_h, ws1, slot_bytes, wss, (const uint32_t *)w.rows, n_rows);
+        const EncSelfHeader sh{w.rows, n_rows, out, slot_bytes, status, lat_w, lat_h, lat_c, img_w, img_h};
         hipLaunchKernelGGL(k_ransw_encode, dim3(ns, n_images), dim3(64), 0, stream, latents, n, ns, w.freq, w.scratch, w.lens,
-                           (size_t)n, ws1, wss);
+                           (size_t)n, ws1, wss, sh);
         hipLaunchKernelGGL(k_compact_self, dim3(ns, n_images), dim3(256), 0, stream, w.scratch, w.lens, out, wcap, ns, ws1, slot_bytes,
                            status, fixed);
         return hipGetLastError() == hipSuccess ? SICN_OK : SICN_ENODEV;
@@ -1343,9 +1504,18 @@ extern "C" int sicn_codec_decode_batch_async_sl(const uint8_t *containers, size_
         uint32_t *serr = w.lens;                                           // [ns]
         unsigned long long *ssum = (unsigned long long *)w.scratch;        // [2 ns]; the scratch slots (>= 2304 B each) are idle in a decode
         const uint32_t *vb = valid_dev_or_null ? &valid_dev_or_null->bytes : (const uint32_t *)nullptr;
-        if (ns)
-            hipLaunchKernelGGL(k_ransw_decode, dim3(ns, n_images), dim3(64), 0, stream, payload, freq_bytes, (const uint32_t *)nullptr, n, ns,
-                               latents, serr, slot_bytes, ws1, latent_stride, containers + 40, (const uint32_t *)nullptr, ssum, wss, vb, 2u, 1);
+        if (ns) {
+            // the latency form (one 16 KB table, one LDS round trip less per step) while all waves of the batch fit the chip at
+            // five per CU; beyond that the two-table form, whose lookups the other eleven waves of a CU hide
+            sicn::ChipGeom chip;
+            const bool big = sicn::chip_geom(&chip) == SICN_OK && (unsigned long long)ns * n_images <= 5ull * (unsigned)chip.n_cu;
+            if (big)
+                hipLaunchKernelGGL(k_ransw_decode<true>, dim3(ns, n_images), dim3(64), 0, stream, payload, freq_bytes, (const uint32_t *)nullptr, n, ns,
+                                   latents, serr, slot_bytes, ws1, latent_stride, containers + 40, (const uint32_t *)nullptr, ssum, wss, vb, 2u, 1);
+            else
+                hipLaunchKernelGGL(k_ransw_decode<false>, dim3(ns, n_images), dim3(64), 0, stream, payload, freq_bytes, (const uint32_t *)nullptr, n, ns,
+                                   latents, serr, slot_bytes, ws1, latent_stride, containers + 40, (const uint32_t *)nullptr, ssum, wss, vb, 2u, 1);
+        }
         hipLaunchKernelGGL(k_dec_finish_self, dim3(1, n_images), dim3(256), 0, stream, containers, vb, 2u, serr, ssum, (uint32_t *)status_dev,
                            n, ns, lat_w, lat_h, lat_c, slot_bytes, ws1, wss);
         return hipGetLastError() == hipSuccess ? SICN_OK : SICN_ENODEV;
@@ -1359,7 +1529,7 @@ extern "C" int sicn_codec_decode_batch_async_sl(const uint8_t *containers, size_
                        (uint8_t *)nullptr, (uint8_t *)nullptr, ws1, slot_bytes, wstream_cap(wss), w.meta + 3, (uint32_t *)nullptr, 0u,
                        (const uint32_t *)w.meta);
     if (ns)
-        hipLaunchKernelGGL(k_ransw_decode, dim3(ns, n_images), dim3(64), 0, stream, payload, freq_bytes, w.offsets, n, ns, latents,
+        hipLaunchKernelGGL(k_ransw_decode<false>, dim3(ns, n_images), dim3(64), 0, stream, payload, freq_bytes, w.offsets, n, ns, latents,
                            w.meta + 3, slot_bytes, ws1, latent_stride, containers + 40, w.meta, w.sums, wss);
     hipLaunchKernelGGL(k_dec_finish, dim3(1, n_images), dim3(64), 0, stream, w.meta, w.hist, w.sums, w.offsets, (uint32_t *)status_dev,
                        n, ns, ws1);

@@ -20,8 +20,10 @@ from typing import Callable, Dict, List, Sequence
 
 import numpy as np
 
-__all__ = ["shard_indices", "checksum", "checksum_t", "run_sharded", "run_sharded_tensors", "broadcast_params", "band_plan",
-           "forward_banded", "forward_banded_tensors", "BandedNet", "BAND_HALO"]
+# the device-resident forms are the product; `run_sharded` / `forward_banded` (numpy in, numpy out, one host hop per image) stay
+# importable as the vehicles of the oracle-injected CPU tests (tests/test_dist_sharding.py) but are not part of the public surface
+__all__ = ["shard_indices", "checksum", "checksum_t", "run_sharded_tensors", "broadcast_params", "band_plan",
+           "forward_banded_tensors", "BandedNet", "BAND_HALO"]
 
 
 def shard_indices(n_images: int, rank: int, world: int) -> List[int]:

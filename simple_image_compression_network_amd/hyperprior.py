@@ -75,7 +75,7 @@ def hyper_descs(lat_w: int, lat_h: int):
 
 class HyperpriorCodec:
     def __init__(self, width: int, height: int, n_images: int, seed: int = 0, device="cuda", use_gdn: bool = True,
-                 main_params=None, options=None):
+                 main_params=None, options=None, z_stream_symbols=None):
         import torch
         rng = np.random.default_rng(seed)
         self.n, self.width, self.height = int(n_images), int(width), int(height)
@@ -105,9 +105,10 @@ class HyperpriorCodec:
         self.s_full = torch.empty((n,) + ds[-1].out_shape, **u8)     # 2 * ceil(./2) >= the latent's size: cropped below
         self.s = torch.empty_like(self.y)
         self.y_hat = torch.empty_like(self.y)
-        # the hyper-latent is small (4K: 261 k symbols = 16 streams of 16384 per image): the longest stream length that still
-        # fills the chip (codec.auto_stream_symbols; the container records it, decoders built like this one pick the same)
-        self.z_coder = codec.LatentCoder(n, zh, zw, zc, width, height, device=self.device, stream_symbols="auto")
+        # the hyper-latent is small (4K: 261 k symbols): codec.auto_stream_symbols picks its stream length from ONE image's latent,
+        # so a container set written by a batch of 8 decodes in a batch of 1; `z_stream_symbols` overrides it and is
+        # then part of the format the decoder must be built with
+        self.z_coder = codec.LatentCoder(n, zh, zw, zc, width, height, device=self.device, stream_symbols=z_stream_symbols or "auto")
         self.y_coder = codec.ContextCoder(n, lat_h, lat_w, lat_c, width, height, device=self.device)
         for net in (self.main, self.h_a, self.h_s):
             net.workspace(n)

@@ -7,10 +7,15 @@
 // Also checks conv2d_layer0 and deconv2d_layer4 (the reference's commented-out unit tests,
 // tb:115-285 and tb:300-509) against the same golden chain.
 //
-// usage: tb_eight_layers_net <param_weights.bin> [width height] [seed]   (seed > 0: random image)
+// At the reference's OWN size (768 x 512, config_nonsquare.h:5-7, all-ones stimulus, tb:781-821) the naive golden model would
+// take minutes, so `direct` selects the oracle's OpenMP closed form (sicn_or_layer_direct: the same bytes, held to the naive
+// model and to the reference-compiled vectors by tests/test_oracle_golden.py) as the golden chain.
+//
+// usage: tb_eight_layers_net <param_weights.bin> [width height] [seed] [direct]   (seed > 0: random image)
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "sicn_hls.hpp"
@@ -20,6 +25,7 @@ extern "C" {
 typedef sicn_layer_desc sicn_or_layer_desc;
 int sicn_or_naive_conv2d(const sicn_or_layer_desc *, const uint64_t *, const int8_t *, const uint8_t *, uint8_t *);
 int sicn_or_naive_deconv2d(const sicn_or_layer_desc *, const uint64_t *, const int8_t *, const uint8_t *, uint8_t *);
+int sicn_or_layer_direct(const sicn_or_layer_desc *, const uint64_t *, const int8_t *, const uint8_t *, uint8_t *, int threads);
 }
 
 using namespace sicn_hls;
@@ -31,6 +37,7 @@ int main(int argc, char **argv)
     if (argc < 2) { std::fprintf(stderr, "usage: %s param_weights.bin [w h] [seed]\n", argv[0]); return 2; }
     const int W = argc > 3 ? std::atoi(argv[2]) : 768, H = argc > 3 ? std::atoi(argv[3]) : 512;
     const unsigned seed = argc > 4 ? (unsigned)std::atoi(argv[4]) : 0;
+    const bool direct = argc > 5 && std::string(argv[5]) == "direct";
     Context::load_params(argv[1]);
     Context::set_image_size(W, H);
     std::printf("Input image size is %d X %d X 3\n", W, H);
@@ -56,8 +63,9 @@ int main(int argc, char **argv)
         const LayerParams &p = Context::get().layer(l);
         golden[l].resize((size_t)d.OFM_ROW * d.OFM_COL * d.OFM_CH);
         std::printf("layer%d verification computation begin. \n", l);
-        int rc = d.transposed ? sicn_or_naive_deconv2d(&d, p.weights.m_weights.data(), p.bias.data(), cur, golden[l].data())
-                              : sicn_or_naive_conv2d(&d, p.weights.m_weights.data(), p.bias.data(), cur, golden[l].data());
+        int rc = direct ? sicn_or_layer_direct(&d, p.weights.m_weights.data(), p.bias.data(), cur, golden[l].data(), 16)
+                 : d.transposed ? sicn_or_naive_deconv2d(&d, p.weights.m_weights.data(), p.bias.data(), cur, golden[l].data())
+                                : sicn_or_naive_conv2d(&d, p.weights.m_weights.data(), p.bias.data(), cur, golden[l].data());
         if (rc) { std::printf("golden model failed rc=%d\n", rc); return 2; }
         std::printf("layer%d verification computation complete. \n", l);
         cur = golden[l].data();

@@ -114,17 +114,17 @@ def test_stream_length_is_an_encoder_parameter(ss):
 
 
 def test_auto_stream_length_policy():
-    """codec.auto_stream_symbols: the longest admissible stream that still gives the chip about two waves per CU."""
+    """codec.auto_stream_symbols: a function of ONE image's latent (never of the batch: a container set written by a batch of 8
+    must decode in a batch of 1) — the format's 16384 for latents of >= 128 such streams, 8192 (+ 2.8 % bytes, half
+    the serial chain) below."""
     from simple_image_compression_network_amd import codec
     n4k, n1080, nz = 135 * 240 * 192, 68 * 120 * 192, 34 * 60 * 128
-    assert codec.auto_stream_symbols(n4k, 8) == 16384          # 8 x 4K latents: 3040 streams of the default length
-    assert codec.auto_stream_symbols(n4k, 1) == 8192           # one 4K latent: 380 streams of 16384 would half-fill the chip
-    assert codec.auto_stream_symbols(n1080, 1) == 2048         # one 1080p latent: 765 streams
-    assert codec.auto_stream_symbols(nz, 8) == 4096            # the hyperprior's hyper-latents of 8 x 4K
-    assert codec.auto_stream_symbols(1000, 1) == 1024 and codec.auto_stream_symbols(0, 1) == 1024
-    for n in (1, 12345, n1080, n4k):
-        for k in (1, 3, 8):
-            assert codec.auto_stream_symbols(n, k) in (1024, 2048, 4096, 8192, 16384)
+    for k in (1, 3, 8):
+        assert codec.auto_stream_symbols(n4k, k) == 16384          # 380 streams per image
+        assert codec.auto_stream_symbols(n1080, k) == 8192         # 192 streams
+        assert codec.auto_stream_symbols(nz, k) == 8192            # the hyperprior's hyper-latent of a 4K image
+        assert codec.auto_stream_symbols(1000, k) == 8192 and codec.auto_stream_symbols(0, k) == 8192
+    assert codec.auto_stream_symbols(128 * 16384) == 16384 and codec.auto_stream_symbols(128 * 16384 - 1) == 8192
 
 
 def test_rejects_symbols_over_127_and_corruption():
@@ -420,7 +420,7 @@ def test_gpu_async_pair_equals_sync_and_oracle():
     lats.append(_skewed_latent(rng, n, 0.9313).reshape(shape))
     lat = np.stack(lats)
     dev = torch.from_numpy(lat).cuda()
-    coder = codec.LatentCoder(lat.shape[0], *shape, image_width=160, image_height=144)
+    coder = codec.LatentCoder(lat.shape[0], *shape, image_width=160, image_height=144, stream_symbols=16384)   # what the synchronous calls use
     coder.encode(dev)
     back = torch.empty_like(dev)
     coder.decode(back)
@@ -448,7 +448,7 @@ def test_gpu_stream_length_parameter_equals_oracle(ss):
     dev = torch.from_numpy(lat).cuda()
     coder = codec.LatentCoder(3, *shape, image_width=480, image_height=272, stream_symbols=ss)
     if ss == "auto":
-        assert coder.stream_symbols == codec.auto_stream_symbols(lat[0].size, 3) == 2048
+        assert coder.stream_symbols == codec.auto_stream_symbols(lat[0].size, 3) == 8192
     ssv = coder.stream_symbols
     coder.encode(dev)
     back = torch.empty_like(dev)
@@ -590,3 +590,29 @@ def test_gpu_coded_pipeline_is_graph_capturable():
     ref_out, ref_lat = net.forward(x)
     torch.cuda.synchronize()
     assert torch.equal(out, ref_out) and torch.equal(lat2, ref_lat)
+
+
+@gpu
+def test_gpu_1080p_sized_container_equals_oracle_at_the_auto_stream_length():
+    """BASELINE.json configs[2] includes the coder: a container of the 1080p latent's size (68 x 120 x 192 = 1.57 M symbols, 192
+    streams at the automatic length of 8192) byte-identical to the oracle's, round trip exact (on the GPU that
+    size used to be covered by round trip + transform hashes only)."""
+    import torch
+    from simple_image_compression_network_amd import codec
+    rng = np.random.default_rng(1080)
+    shape = (68, 120, 192)
+    lat = np.stack([_mock_latent(rng, shape, zero_frac=0.5)])
+    dev = torch.from_numpy(lat).cuda()
+    coder = codec.LatentCoder(1, *shape, image_width=1920, image_height=1080)      # default = "auto"
+    assert coder.stream_symbols == 8192
+    coder.encode(dev)
+    back = torch.empty_like(dev)
+    coder.decode(back)
+    coder.check()
+    assert torch.equal(back, dev)
+    size = coder.sizes()[0]
+    blob = coder.slots[0, :size].cpu().numpy().tobytes()
+    ref = c_oracle.codec_encode(lat[0], (1920, 1080), 3, stream_symbols=8192)
+    assert blob == ref
+    got, info = codec.decode_latent(coder.slots[0, :size].clone())
+    assert int(info.stream_symbols) == 8192 and int(info.n_streams) == 192 and np.array_equal(got.cpu().numpy(), lat[0])

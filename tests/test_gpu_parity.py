@@ -616,7 +616,9 @@ def test_cpp_testbench_mirrors_reference_test():
     exe = ROOT / "tests" / "cpp" / "tb_eight_layers_net"
     params = ROOT / "simple_image_compression_network_amd" / "data" / "param_weights.bin"
     assert exe.exists() and params.exists(), "run __graft_entry__.build() first"
-    for args in (["192", "128"], ["96", "80", "7"]):
+    # the last run is the reference's own test at its own size: 768 x 512, all ones (config_nonsquare.h:5-7,
+    # conv3_nonsquare_tb.cpp:781-821), golden chain by the oracle's OpenMP direct form
+    for args in (["192", "128"], ["96", "80", "7"], ["768", "512", "0", "direct"]):
         r = subprocess.run([str(exe), str(params)] + args, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         assert "Image # 0 passed the testing." in r.stdout

@@ -103,3 +103,38 @@ def test_gpu_hyperprior_decoder_needs_only_the_containers():
     dec.decode(out, z_slots=zc.clone(), y_slots=yc.clone(), z_valid=enc.z_coder.enc_status.clone(), y_valid=enc.y_coder.enc_status.clone())
     dec.check()
     assert torch.equal(out, ref)
+
+
+@gpu
+def test_gpu_hyperprior_containers_do_not_depend_on_the_batch_size():
+    """the hyper-latent coder's stream length used to be chosen from the BATCH (auto_stream_symbols(n, n_images)), so a
+    container set written by HyperpriorCodec(n = 8) could not be read by HyperpriorCodec(n = 1).  The choice is a function of one
+    image's latent now: encode a batch, decode every image of it alone, byte-identical containers either way."""
+    import torch
+    from simple_image_compression_network_amd.hyperprior import HyperpriorCodec
+    w, h, n = 160, 112, 3
+    enc = HyperpriorCodec(w, h, n, seed=5)
+    one = HyperpriorCodec(w, h, 1, seed=5)
+    assert enc.z_coder.stream_symbols == one.z_coder.stream_symbols
+    x = torch.from_numpy(np.random.default_rng(2).integers(0, 256, (n, h, w, 3), dtype=np.uint8)).cuda()
+    zc, yc = enc.encode(x)
+    ref = torch.empty((n,) + enc.main.descs[-1].out_shape, dtype=torch.uint8, device="cuda")
+    enc.decode(ref)
+    enc.check()
+    zs, ys = enc.z_coder.sizes(), enc.y_coder.sizes()
+    for i in range(n):
+        z1, y1 = one.encode(x[i:i + 1])
+        one.check()
+        assert one.z_coder.sizes()[0] == zs[i] and torch.equal(z1[0, :zs[i]], zc[i, :zs[i]])
+        assert one.y_coder.sizes()[0] == ys[i] and torch.equal(y1[0, :ys[i]], yc[i, :ys[i]])
+        out = torch.empty_like(ref[i:i + 1])
+        one.decode(out, z_slots=zc[i:i + 1].clone(), y_slots=yc[i:i + 1].clone())      # the batch's containers, decoded alone
+        one.check()
+        assert torch.equal(out, ref[i:i + 1])
+
+
+@gpu
+def test_gpu_hyperprior_pipeline_equals_oracle_at_1080p():
+    """The stage-by-stage check at BASELINE.json's 1080p size: latent 120 x 68 x 192 (odd rounding: 1080 / 16
+    = 67.5), every layer on the kernels the 1080p config really runs, GDN / IGDN on tensors of up to 66 MB."""
+    _pipeline_against_oracle((1920, 1080), True, 1)
