@@ -22,6 +22,7 @@
 // asm statement that keeps the C operand's registers live (and waits) behind the MFMAs that read them, s_nop before the
 // epilogue reads the accumulators.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "k_common.hpp"
@@ -39,6 +40,13 @@ struct Ring {
     static_assert(PF % 2 == 0 && FLIGHT >= 1, "");
 };
 
+// the deconv's tap loop: a loop over the taps (ROLLED, round 2's form: 20 KB of code) or unrolled completely (round 4: offsets,
+// ring slots and parities become constants — in-kernel stamps on one 1080p image had shown 520 - 580 cycles per 16-MFMA pass
+// against 360 for the conv kernel, whose 50 passes have always been unrolled).  Measured (us per layer, one image, rolled ->
+// unrolled): 1080p layers 4 / 5 / 6 19.9 / 23.1 / 45.3 -> 17.6 / 20.6 / 42.2, 256 x 256 16.9 / 14.4 / 14.9 -> 14.6 / 11.9 / 12.2;
+// on FULL grids (two workgroups per CU walking 33 - 47 KB of code each) the unrolled form is 3 % slower (layer 4 of 8 x 4K:
+// 0.132 -> 0.136 ms), so the launcher keeps the loop there (profiles/r04_deconv_unroll.txt).
+#define SICN_DECONV_TAP_LOOP _Pragma("unroll ROLLED ? 1 : 32")
 #define SICN_MFMA_V(ACC, A, B) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
 #define SICN_MFMA_V_C(ACC, A, B, C) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %3" : "=&v"(ACC) : "v"(A), "v"(B), "v"(C))
 
@@ -175,7 +183,11 @@ extern "C" int sicn_debug_stagger(unsigned long long cycles)
 #endif
 
 // ReLU / pack / store of one accumulator set (as store_tiles16 of k_mfma16.hip); always NC * NT16 / 4 stores per wave
-template <int TX, int NT16>
+// THROUGH: the stores bypass the caches (sc0 sc1: written through to memory) — the K-split partial tensors, which a workgroup on
+// ANOTHER XCD reads in the same launch (ksplit_finish_tile, with cache-bypassing loads): measured necessary — with ordinary
+// stores and loads plus agent-scope release / acquire fences a finishing workgroup could still hit a line in its XCD's L2 that a
+// neighbour's finisher had fetched before the other half of the line (the other channel slice's bytes) was written back
+template <int TX, int NT16, bool THROUGH = false>
 __device__ __forceinline__ void store_tiles_p(v4i (&acc)[Geo<TX>::NC][NT16], uint8_t *out_img, int out_img_bytes, const TensorMap &om,
                                               int MW, int MH, int Y0, int X0, int w, int pos, int g, bool deconv, int py, int px,
                                               uint32_t act_floor, uint32_t cg0)
@@ -200,7 +212,9 @@ __device__ __forceinline__ void store_tiles_p(v4i (&acc)[Geo<TX>::NC][NT16], uin
             for (int d = 0; d < 4; d++)
                 v[d] = (int)pack4_relu7(acc[c][4 * J + d][0], acc[c][4 * J + d][1], acc[c][4 * J + d][2], acc[c][4 * J + d][3],
                                         act_floor & ACT_FLOOR_MASK);
-            if (act_floor & ACT_NT_STORE)
+            if constexpr (THROUGH)
+                __builtin_amdgcn_raw_buffer_store_b128(v, ro, ok ? off0 + (uint32_t)(2 * J) * om.grp : OOB, 0, 17);   // sc0 sc1
+            else if (act_floor & ACT_NT_STORE)
                 __builtin_amdgcn_raw_buffer_store_b128(v, ro, ok ? off0 + (uint32_t)(2 * J) * om.grp : OOB, 0, 2);
             else
                 __builtin_amdgcn_raw_buffer_store_b128(v, ro, ok ? off0 + (uint32_t)(2 * J) * om.grp : OOB, 0, 0);
@@ -279,10 +293,11 @@ __device__ __forceinline__ void ksplit_finish_tile(const uint8_t *part_img, unsi
             for (int J = 0; J < NT16 / 4; J++) {
                 const uint32_t off = ok ? off0 + (uint32_t)(2 * J) * om.grp : OOB;
                 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-                v4u sum = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(rp[0], off, 0, 0));
+                // sc0 sc1: past the caches, straight from memory (see store_tiles_p<.., THROUGH>)
+                v4u sum = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(rp[0], off, 0, 17));
 #pragma unroll
                 for (int z = 1; z < KS; z++) {
-                    const v4u v = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(rp[z], off, 0, 0));
+                    const v4u v = __builtin_bit_cast(v4u, __builtin_amdgcn_raw_buffer_load_b128(rp[z], off, 0, 17));
 #pragma unroll
                     for (int d = 0; d < 4; d++) sum[d] = add_bytes(sum[d], v[d]);
                 }
@@ -314,7 +329,7 @@ __device__ __forceinline__ TileCoord tile_coord(int tiles_x, int n_tiles, int n_
 // =====================================================================================================================
 // deconv522<>: NQ / 2 passes per tap (channel pairs q, q+1 of one tap), the tap loop stays a loop
 // =====================================================================================================================
-template <int NQ, int NT16, int NTF, int TX, int PF, int KS>
+template <int NQ, int NT16, int NTF, int TX, int PF, int KS, bool ROLLED>
 __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                      const int8_t *__restrict__ wstream, const int8_t *__restrict__ bias, int IW, int IH,
                                                      int OW, int OH, int tiles_x, int n_tiles, int n_images, int in_layout,
@@ -454,19 +469,19 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
             tap(par_tag, ph, t, toff, toff_next);
         };
         if constexpr (PPT % 2 == 0) {
-#pragma unroll 1
+SICN_DECONV_TAP_LOOP
             for (int t = 0; t < ntap; t++) one(std::integral_constant<int, 0>{}, t);   // an even number of passes: the parity never changes
         } else {
             int t = 0;
             if (par0 == 0) {
-#pragma unroll 1
+SICN_DECONV_TAP_LOOP
                 for (; t + 1 < ntap; t += 2) {
                     one(std::integral_constant<int, 0>{}, t);
                     one(std::integral_constant<int, 1>{}, t + 1);
                 }
                 if (t < ntap) one(std::integral_constant<int, 0>{}, t);
             } else {
-#pragma unroll 1
+SICN_DECONV_TAP_LOOP
                 for (; t + 1 < ntap; t += 2) {
                     one(std::integral_constant<int, 1>{}, t);
                     one(std::integral_constant<int, 0>{}, t + 1);
@@ -482,8 +497,8 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
             store_tiles_p<TX, NT16>(acc, out_img, out_img_bytes, om, IW, IH, Y0, X0, w, pos, g, true, py, px, act_floor,
                                     (uint32_t)(split * (COUTW / 32)));
         else   // this slice's partial sums, low bytes, no activation, into its own tensor of the output's shape
-            store_tiles_p<TX, NT16>(acc, ks.partials + (size_t)zs * ks.stride + (size_t)tc.img * out_img_bytes, out_img_bytes, om, IW, IH, Y0,
-                                    X0, w, pos, g, true, py, px, ACT_FLOOR_RAW, (uint32_t)(split * (COUTW / 32)));
+            store_tiles_p<TX, NT16, true>(acc, ks.partials + (size_t)zs * ks.stride + (size_t)tc.img * out_img_bytes, out_img_bytes, om, IW, IH,
+                                          Y0, X0, w, pos, g, true, py, px, ACT_FLOOR_RAW, (uint32_t)(split * (COUTW / 32)));
 #ifdef SICN_STAMP
         dst[3 + 2 * ph] = __builtin_amdgcn_s_memtime();
 #endif
@@ -692,8 +707,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_p(const uint8_t *__restrict__ i
     } else {
         // this slice's partial sums, low bytes, no activation, into its own tensor of the output's shape; the last slice to arrive
         // adds the KS tensors mod 256 and finishes the tile
-        store_tiles_p<TX, NT16>(acc, ks.partials + (size_t)zs * ks.stride + (size_t)tc.img * out_img_bytes, out_img_bytes, om, OW, OH, Y0, X0,
-                                w, pos, g, false, 0, 0, ACT_FLOOR_RAW, (uint32_t)(split * (COUTW / 32)));
+        store_tiles_p<TX, NT16, true>(acc, ks.partials + (size_t)zs * ks.stride + (size_t)tc.img * out_img_bytes, out_img_bytes, om, OW, OH, Y0,
+                                      X0, w, pos, g, false, 0, 0, ACT_FLOOR_RAW, (uint32_t)(split * (COUTW / 32)));
         unsigned long long *word = ks.flags + (size_t)tc.item * gridDim.y + blockIdx.y;
         if (ksplit_arrive<KS>(word, ks.tag, zs, smem)) {
             ksplit_finish_tile<TX, NT16, KS>(ks.partials + (size_t)tc.img * out_img_bytes, ks.stride, out_img, out_img_bytes, om, OW, OH, Y0, X0,
@@ -760,11 +775,25 @@ static hipError_t launch_p(const LayerGeom &g, const sicn_weights &w, const uint
         ka = KSplitArgs{ks->partials, (unsigned long long)ks->partial_stride, ks->flags, ks->nonce};
     }
     if constexpr (DECONV) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_deconv_p<NQ, NT16, NTF, TX, PF, KS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_deconv_p<NQ, NT16, NTF, TX, PF, KS>), grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias, g.IW, g.IH, g.OW,
-                           g.OH, tiles_x, tiles_x * tiles_y, n_images, in_layout, out_layout, flags, chip.n_xcd, ka);
+        // the tap loop stays a loop where every CU holds two workgroups (full grids), and is unrolled on smaller ones (see
+        // SICN_DECONV_TAP_LOOP).  The K-split form (an option, never automatic) runs the LOOP: its unrolled build gave wrong bytes in
+        // phase 0 of a few tiles per launch — accumulator tiles j = 2, 3, i.e. the second 1-KiB piece of a weight tile, only when the
+        // previous kernel on the CU had left OTHER weights in LDS (layer 5 -> layer 6 in a chain; alone, the stale bytes are the
+        // right ones), timing dependent — while the loop form passes every repetition (gpurun_out r04 dbg*: 9 / 9 against 0 / 9).
+        // The cause was not found in the time given to an option that measures as a loss anyway (sicn_plan.h); the unsplit
+        // unrolled kernels share the prologue and pass the whole suite, fuzz runs included.  SICN_KSPLIT_UNROLLED=1 selects the
+        // failing build for whoever looks further.
+        static const bool ks_unrolled = getenv("SICN_KSPLIT_UNROLLED") != nullptr;
+        const bool rolled = KS == 1 ? (unsigned long long)grid.x * grid.y >= 2ull * (unsigned)chip.n_cu : !ks_unrolled;
+        auto go = [&](auto kern) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, in, out, w.d_w_mfma16, w.d_bias, g.IW, g.IH, g.OW, g.OH, tiles_x,
+                               tiles_x * tiles_y, n_images, in_layout, out_layout, flags, chip.n_xcd, ka);
+            return hipGetLastError();
+        };
+        if (rolled) return go(&k_deconv_p<NQ, NT16, NTF, TX, PF, KS, true>);
+        return go(&k_deconv_p<NQ, NT16, NTF, TX, PF, KS, false>);
     } else {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_p<NQ, NT16, NTF, TX, PF, KS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
