@@ -128,6 +128,11 @@ const char *sicn_strerror(int code);
  * (0 generic, 1 mfma conv, 2 mfma deconv, 3 layer 0, 4 layer 7), mfma family (0 plain, 1 pipelined, 2 wide persistent), tile_x,
  * split_n, split_k, grid x, grid y, grid z, strip chunks, layer-0 tiles per run }.  sicn_debug_xcd_item is the host mirror of
  * the kernels' workgroup -> work item mapping (-1: padding workgroup). */
+/* dst[n][h][w][c] = the top-left h x w corner of every image of src[n][src_h][src_w][c] (device pointers, one launch, enqueue
+ * only).  A deconv522 doubles a size that a conv2d rounded up, so a tensor rebuilt by deconvs can be one row / column larger than
+ * the one it mirrors (the hyperprior's scale map against the latent); this is the crop. */
+int sicn_crop_nhwc(const uint8_t *src, uint8_t *dst, int n_images, int src_h, int src_w, int h, int w, int channels,
+                   void *hip_stream);
 int sicn_debug_plan(const sicn_layer_desc *desc, int n_images, const sicn_options *opt, int n_cu, int32_t out[12]);
 long long sicn_debug_xcd_item(long long block, long long n_items, int n_xcd);
 int sicn_validate_desc(const sicn_layer_desc *desc); /* pure host check, no GPU needed         */

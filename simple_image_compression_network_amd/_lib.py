@@ -56,6 +56,7 @@ ABI = {
     "sicn_eight_layers_net": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "sicn_net_profile": (_i, [_vp, _i]),
     "sicn_net_layer_ms": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i)]),
+    "sicn_crop_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sicn_debug_plan": (_i, [_descp, _i, ctypes.POINTER(COptions), _i, ctypes.POINTER(ctypes.c_int32)]),
     "sicn_debug_xcd_item": (ctypes.c_longlong, [ctypes.c_longlong, ctypes.c_longlong, _i]),
 }

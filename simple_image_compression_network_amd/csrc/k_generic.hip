@@ -57,4 +57,37 @@ hipError_t launch_generic(const LayerGeom &g, const sicn_weights &w, const uint8
     return hipGetLastError();
 }
 
+// ---- crop of a batch of NHWC tensors: dst[n][h][w][c] = src[n][y < h][x < w][c] of [n][hs][ws][c], ONE launch ------------------
+// (a deconv522 doubles a size that a conv2d rounded up, so a decoded map can be one row / column larger than the tensor it models:
+// the hyperprior's scale map.  torch's strided copy_ did this as one D2D memcpy per image: 16 launches of ~50 us per 8 x 4K step.)
+__global__ __launch_bounds__(256) void k_crop_nhwc(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int n, int hs, int ws,
+                                                   int h, int w, int c, int vec)
+{
+    const size_t row_dst = (size_t)w * c, row_src = (size_t)ws * c;
+    if (vec) {   // rows of both tensors are multiples of 16 bytes and both bases are 16-byte aligned
+        const size_t q_row = row_dst / 16, total = (size_t)n * h * q_row;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            const size_t r = i / q_row, q = i - r * q_row, img = r / h, y = r - img * h;
+            reinterpret_cast<uint4 *>(dst)[i] = *reinterpret_cast<const uint4 *>(src + ((img * hs + y) * row_src) + q * 16);
+        }
+    } else {
+        const size_t total = (size_t)n * h * row_dst;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            const size_t r = i / row_dst, b = i - r * row_dst, img = r / h, y = r - img * h;
+            dst[i] = src[(img * hs + y) * row_src + b];
+        }
+    }
+}
+
+hipError_t launch_crop_nhwc(const uint8_t *src, uint8_t *dst, int n, int hs, int ws, int h, int w, int c, hipStream_t stream)
+{
+    const size_t row_dst = (size_t)w * c, row_src = (size_t)ws * c;
+    const int vec = row_dst % 16 == 0 && row_src % 16 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    const size_t items = (size_t)n * h * (vec ? row_dst / 16 : row_dst);
+    if (items == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>((items + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_crop_nhwc, dim3(blocks), dim3(256), 0, stream, src, dst, n, hs, ws, h, w, c, vec);
+    return hipGetLastError();
+}
+
 }  // namespace sicn

@@ -662,6 +662,17 @@ extern "C" int sicn_net_layer_ms(sicn_net *net, int reset, float *ms_sum, int *l
     return SICN_OK;
 }
 
+// ---- crop of NHWC batches (one launch; see k_crop_nhwc) -----------------------------------------------------------------------------
+extern "C" int sicn_crop_nhwc(const uint8_t *src, uint8_t *dst, int n_images, int src_h, int src_w, int h, int w, int channels,
+                              void *hip_stream)
+{
+    if (n_images < 0 || h < 0 || w < 0 || channels <= 0 || h > src_h || w > src_w) return SICN_EINVAL;
+    if ((size_t)n_images * h * w && (!src || !dst)) return SICN_EINVAL;
+    if (chip_geom(nullptr) != SICN_OK) return SICN_ENODEV;
+    const hipError_t e = launch_crop_nhwc(src, dst, n_images, src_h, src_w, h, w, channels, (hipStream_t)hip_stream);
+    return e == hipSuccess ? SICN_OK : SICN_ENODEV;
+}
+
 // ---- launch planning, inspectable without a GPU (tests/test_abi_load.py): what would this layer launch on a chip of n_cu CUs? ----
 extern "C" int sicn_debug_plan(const sicn_layer_desc *d, int n_images, const sicn_options *opt, int n_cu, int32_t out[12])
 {

@@ -95,6 +95,8 @@ int chip_geom(ChipGeom *out);
 // relu = false: store the lane BEFORE the sign-bit ReLU (input of the GDN extension, include/sicn_gdn.h)
 hipError_t launch_generic(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
                           int n_images, hipStream_t stream, bool relu = true);
+// k_generic.hip: dst[n][h][w][c] = the top-left h x w corner of src[n][hs][ws][c], one launch
+hipError_t launch_crop_nhwc(const uint8_t *src, uint8_t *dst, int n, int hs, int ws, int h, int w, int c, hipStream_t stream);
 // in_layout / out_layout: LAYOUT_NHWC (the ABI layout) / LAYOUT_GROUP / LAYOUT_PHASE (k_common.hpp)
 hipError_t launch_mfma(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out,
                        int n_images, hipStream_t stream, int in_layout, int out_layout);

@@ -115,9 +115,13 @@ class HyperpriorCodec:
 
     def _scale_map(self, z):
         """h_s(z) cropped to the latent's shape (deconv doubles a size that conv rounded up)."""
+        import ctypes
         self.h_s.run_layers(0, 1, z, out=self.s_full)
-        _, h, w, _ = self.y.shape
-        self.s.copy_(self.s_full[:, :h, :w, :])
+        n, h, w, c = self.y.shape
+        _, hs, ws, _ = self.s_full.shape
+        # one launch for the batch (torch's strided copy_ was one D2D memcpy per image: ~0.8 ms of an 8 x 4K encode + decode step)
+        api._lib.check(api._lib.lib().sicn_crop_nhwc(ctypes.c_void_p(self.s_full.data_ptr()), ctypes.c_void_p(self.s.data_ptr()), n, hs,
+                                                     ws, h, w, c, api._stream_ptr(None)), "sicn_crop_nhwc")
         return self.s
 
     def encode(self, x):

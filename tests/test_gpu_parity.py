@@ -811,3 +811,18 @@ def test_randomised_sweep_small():
                        capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "60/60 cases bit-exact" in r.stdout and "4/4 chains bit-exact" in r.stdout
+
+
+@pytest.mark.parametrize("shape", [(3, 9, 10, 192, 8, 9), (2, 7, 5, 3, 6, 5), (1, 4, 4, 16, 4, 4), (2, 6, 33, 5, 5, 31)])
+def test_crop_nhwc_one_launch(api, shape):
+    """sicn_crop_nhwc (the hyperprior's scale-map crop): both paths — 16-byte rows and byte rows — against numpy slicing."""
+    from simple_image_compression_network_amd import _lib
+    n, hs, ws, c, h, w = shape
+    src = np.random.default_rng(5).integers(0, 256, (n, hs, ws, c), dtype=np.uint8)
+    d_src, d_dst = _dev(src), torch.zeros((n, h, w, c), dtype=torch.uint8, device="cuda")
+    rc = _lib.lib().sicn_crop_nhwc(ctypes.c_void_p(d_src.data_ptr()), ctypes.c_void_p(d_dst.data_ptr()), n, hs, ws, h, w, c,
+                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d_dst.cpu().numpy(), src[:, :h, :w, :])
+    assert _lib.lib().sicn_crop_nhwc(ctypes.c_void_p(d_src.data_ptr()), ctypes.c_void_p(d_dst.data_ptr()), n, hs, ws, hs + 1, w, c, None) == -22
