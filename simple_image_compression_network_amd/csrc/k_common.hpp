@@ -3,6 +3,18 @@
 #include "sicn_internal.h"
 #include "sicn_plan.h"
 
+// Timing-experiment switches that make a kernel give WRONG results on purpose (what does the barrier / the wait / the pack cost?)
+// live in the kernel sources because they must cut into the middle of a pass; none of them can reach a product build by
+// accident: they refuse to compile without -DSICN_ALLOW_WRONG_RESULTS.
+#if defined(SICN_EXP_NOWAIT) || defined(SICN_EXP_NO_PASS_BARRIER) || defined(SICN_X_NOBAR) || defined(SICN_X_NOWAIT) ||         \
+    defined(SICN_XW_NOREAD) || defined(SICN_XW_NOPACK) || defined(SICN_XW_NOSTORE) || defined(SICN_XW_NOWAIT) ||                \
+    defined(SICN_EXP_L7_DMA_ONLY) || defined(SICN_EXP_L7_READS_ONLY) || defined(SICN_EXP_L7_MFMA_ONLY) ||                      \
+    defined(SICN_EXP_L7_NO_MFMA) || defined(SICN_EXP_L7_NO_BARRIER) || (defined(SICN_EXP_L7_STORE) && SICN_EXP_L7_STORE != 0)
+#ifndef SICN_ALLOW_WRONG_RESULTS
+#error "this switch builds kernels that give wrong results on purpose (timing experiments): add -DSICN_ALLOW_WRONG_RESULTS"
+#endif
+#endif
+
 namespace sicn {
 
 typedef int v4i __attribute__((ext_vector_type(4)));

@@ -201,7 +201,34 @@ def test_gpu_layer_with_gdn_equals_oracle(case, inverse):
 
 
 @gpu
-@pytest.mark.parametrize("options", [{}, {"tile_x": 16}, {"no_phase_layout": 1}, {"force_generic": 1}])
+@pytest.mark.parametrize("grid", [0, 8, 16])
+@pytest.mark.parametrize("case", [(128, 128, 8, 16, 66, 18, 0), (128, 128, 8, 16, 34, 10, 1), (128, 128, 8, 16, 131, 33, 0), (128, 128, 8, 16, 65, 19, 1)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gpu_wide_persistent_layer_with_gdn_equals_oracle(case, inverse, grid):
+    """the wide persistent kernels (k_conv_x / k_deconv_x, chosen automatically from 4 tiles per CU on — i.e. for the
+    hyperprior's main transform at 8 x 4K) hand their accumulators over with the RAW floor when a GDN follows; that path had no
+    oracle comparison (the GDN test sizes never reached the automatic threshold).  Forced here (wave_tile = 128) with 8 / 16 / all
+    workgroups so that every workgroup walks several tiles."""
+    import torch
+    from simple_image_compression_network_amd import api
+    rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + 7 * inverse + grid)
+    d = _mk_desc(*case)
+    W = rng.integers(-8, 8, (d.OFM_CH, 5, 5, d.IFM_CH)).astype(np.int8)
+    b = rng.integers(-128, 128, d.OFM_CH).astype(np.int8)
+    words = sicn_ref.pack_finn_tiles(W, d.SIMD, d.PE)
+    x = rng.integers(0, 256, (2,) + d.in_shape, dtype=np.uint8)
+    beta, gamma = _params(rng, d.OFM_CH)
+    g = api.GDN(beta, gamma, inverse, 12)
+    fpw = api.FixedPointWeights(d.SIMD, 4, d.PE, d.W_TILES, words)
+    fn = api.deconv522 if d.transposed else api.conv2d
+    got = fn(d, fpw, b, torch.from_numpy(x).cuda(), None, 2, gdn=g, options={"wave_tile": 128, "persistent_grid": grid}).cpu().numpy()
+    for i in range(2):
+        pre = sicn_ref.layer_preact_ref(x[i], W, b, d.transposed)
+        assert np.array_equal(got[i], c_oracle.gdn(pre, beta, gamma, inverse, 12)), i
+
+
+@gpu
+@pytest.mark.parametrize("options", [{}, {"tile_x": 16}, {"no_phase_layout": 1}, {"force_generic": 1}, {"wave_tile": 128, "persistent_grid": 8}])
 def test_gpu_gdn_net_all_internal_layouts(options):
     """The hyperprior-style main transform: GDN after L0-L2, IGDN after L4-L6 (L3 and L7 keep the reference's ReLU), as one
     sicn_net chain.  The activations run in place on GROUP / PHASE / NHWC intermediates; latent and reconstruction must
