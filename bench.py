@@ -155,6 +155,8 @@ def parse():
     ap.add_argument("--no-host-io", action="store_true", help="skip the secondary host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary small configs (BASELINE.json configs[1], [2])")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained region")
+    ap.add_argument("--sustained", action="store_true", help="with --headline-only: keep the >= 2 s sustained region (its clock / power "
+                                                             "samples are the steady-state ones; it launches nothing but the 8 layers)")
     ap.add_argument("--headline-only", action="store_true",
                     help="the timed loop and the per-layer table only (what profiles/collect_pmc.sh runs under rocprofv3)")
     ap.add_argument("--cpu-sample", type=int, nargs=2, default=[256, 256], metavar=("W", "H"))
@@ -299,7 +301,8 @@ def small_configs(api, codec, dev):
 def main():
     args = parse()
     if args.headline_only:
-        args.no_coder = args.no_hyperprior = args.no_host_io = args.no_cpu_baseline = args.no_configs = args.no_sustained = True
+        args.no_coder = args.no_hyperprior = args.no_host_io = args.no_cpu_baseline = args.no_configs = True
+        args.no_sustained = not args.sustained
     import torch
     import torch.distributed as dist
 

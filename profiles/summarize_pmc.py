@@ -105,6 +105,8 @@ for k in sorted(set(fetch) | set(write) | set(sq)):
         e["wait_inst_frac"] = round(s.get("SQ_WAIT_INST_ANY", 0) / s["SQ_WAVE_CYCLES"], 3)
     if s.get("SQ_LDS_ACTIVE", 0) > 0:
         e["lds_bank_conflict_frac"] = round(s.get("SQ_LDS_BANK_CONFLICT", 0) / s["SQ_LDS_ACTIVE"], 3)
+        if s.get("GRBM_GUI_ACTIVE", 0) > 0:   # SQ_LDS_ACTIVE sums the CUs' LDS-busy cycles: share of the launch an average CU's LDS was busy
+            e["lds_active_frac"] = round(s["SQ_LDS_ACTIVE"] / 256 / (s["GRBM_GUI_ACTIVE"] / 8), 3)
     kernels[k] = e
 
 # dominant layer of the 8 x 4K bench: the largest average launch in the stats run
@@ -123,6 +125,10 @@ try:
     summary["dominant_kernel_algorithmic_bytes_per_launch"] = b["roofline"]["algorithmic_bytes"]
     summary["dominant_kernel_avg_launch_ms_bench"] = b["roofline"]["avg_launch_ms"]
     summary["bench_under_rocprof"] = {k: b[k] for k in ("value", "ms_per_step", "layers", "output_bit_exact")}
+    # the clock and power the chip held while these numbers were taken (bench.py's side-thread amdsmi sampler)
+    summary["sclk_mhz_mean"] = b["roofline"].get("sclk_mhz_mean")
+    summary["power_w_mean"] = b["roofline"].get("power_w_mean")
+    summary["clocks"] = b.get("clocks")
     best = next((k for k in kernels if k.startswith(f"layer {dom} ")), None)
     if best:
         e = kernels[best]
