@@ -107,7 +107,9 @@ typedef struct sicn_options {
     int32_t split_k;         /* 0: automatic (grids that leave half of the CUs idle even after split_n); 1: never; > 1: always  */
                              /*    where the form exists (the channel-split 8 x 16 kernels inside a net chain, whose workspace  */
                              /*    holds the partial tensors) — K is split into channel-group pairs over workgroups, exact     */
-    int32_t reserved[5];
+    int32_t l7_loader;       /* layer 7 (k_l7): 0 / 1: four waves, every wave requests its share of a step's rows; 2: the        */
+                             /*    loader-wave form k_l7s (a fifth wave issues all row requests)        */
+    int32_t reserved[4];
 } sicn_options;
 
 typedef struct sicn_weights sicn_weights; /* one layer's weights+bias, resident on the device  */

@@ -327,10 +327,15 @@ __device__ unsigned long long g_l7_stamp[8];
 #else
 #define L7_T(i)
 #endif
-__global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
-                                               const int8_t *__restrict__ w_l7,
-                                               const int8_t *__restrict__ bias, int IW, int IH, int OW,
-                                               int OH, int steps_y, int y_chunks, int tiles_x, int n_images, int in_layout, int n_xcd)
+// SPLIT (round 4, VERDICT r3 item 4: "loader wave(s) issuing only LDS-DMA, consumer waves doing reads + MFMA + stores"): the
+// workgroup has a FIFTH wave that issues every row request of a step (what the four waves shared, five apiece, and paid 941 of a
+// step's 3954 cycles for: the requests wait for queue space) and waits for them to land; the four consumer waves never touch
+// vmcnt for a load.  One barrier per step as before.  15 waves per CU need <= 128 VGPRs: the per-tap addressing constants are
+// recomputed instead of kept (18 registers).
+template <bool SPLIT>
+__device__ __forceinline__ void l7_body(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int8_t *__restrict__ w_l7,
+                                        const int8_t *__restrict__ bias, int IW, int IH, int OW, int OH, int steps_y, int y_chunks,
+                                        int tiles_x, int n_images, int in_layout, int n_xcd)
 {
     constexpr int CIN = 128;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -351,16 +356,20 @@ __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ 
 
     // lane roles in v_mfma_i32_16x16x64_i8: A row / B column = lane & 15, K bytes 16*(lane>>4)..+15
     const int m = lane & 15, kg = lane >> 4;
+    const bool loader = SPLIT && w == 4;        // wave-uniform
+    const int wr = SPLIT ? (w & 3) : w;         // the consumer's row inside a step
     v4i wf[18];
+    if (!loader) {
 #pragma unroll
-    for (int s = 0; s < 18; s++) wf[s] = *(const v4i *)(w_l7 + (s * 16 + m) * 64 + kg * 16);
+        for (int s = 0; s < 18; s++) wf[s] = *(const v4i *)(w_l7 + (s * 16 + m) * 64 + kg * 16);
+    }
     const int b0 = bias[0], b1 = bias[1], b2 = bias[2];
 
     const int in_img_bytes = IH * IW * CIN;
     const uint8_t *in_img = in + (size_t)img * in_img_bytes;
     uint8_t *out_img = out + (size_t)img * OH * OW * 3;
     const int py = kg >> 1, px = kg & 1;
-    uint8_t *my_stage = stage + w * L7_STAGE;
+    uint8_t *my_stage = stage + wr * L7_STAGE;
     const bool fast_rows = ((OW * 3) & 3) == 0 && X0 + TILE_X <= IW;
 
     // window row r <-> input row 4*s_begin - 3 + r; rows 0,1 are never read (they only make the
@@ -368,11 +377,20 @@ __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ 
     const int iy_top = 4 * s_begin - 3;
     const int iy_max = min(IH, 4 * s_end + 1);   // last row this chunk reads
     const TensorMap tm = tensor_map(in_layout, CIN, IW, IH);
-    l7_load_rows<9>(patch, scratch, in_img, in_img_bytes, w, lane, 2 * L7_STEP_PIECES, iy_top, max(iy_top + 2, 0), iy_max, 0, X0,
-                    IW, tm);
+    if constexpr (SPLIT) {
+        if (loader) {
+#pragma unroll
+            for (int vw = 0; vw < 4; vw++)
+                l7_load_rows<9>(patch, scratch, in_img, in_img_bytes, vw, lane, 2 * L7_STEP_PIECES, iy_top, max(iy_top + 2, 0), iy_max, 0,
+                                X0, IW, tm);
+        }
+    } else
+        l7_load_rows<9>(patch, scratch, in_img, in_img_bytes, w, lane, 2 * L7_STEP_PIECES, iy_top, max(iy_top + 2, 0), iy_max, 0, X0,
+                        IW, tm);
     // block k = window rows 4k+4 .. 4k+7 = the rows step k adds; blocks 1 .. AHEAD-1 start now
     int pnext = 2 * L7_STEP_PIECES;        // ring piece slot of the next block to be requested
     int ynext = iy_top + 8;                // its first input row
+    static_assert(!SPLIT || L7_AHEAD == 1, "the loader wave keeps one step of rows in flight");
 #pragma unroll
     for (int k = 1; k < L7_AHEAD; k++) {
         l7_load_rows<5>(patch, scratch, in_img, in_img_bytes, w, lane, L7_STEP_PIECES, ynext, 0, iy_max, pnext, X0, IW, tm);
@@ -382,16 +400,38 @@ __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ 
     }
 
     // per-lane fragment addressing: P = (4t + 2 + w + dy)*36 + 16c + m + dx
-    uint32_t fa[9], fs[9];
+    auto frag_a = [&](int tap) { return (uint32_t)((2 + wr + tap / 3) * L7_PITCH + m + tap % 3); };
+    auto frag_s = [&](uint32_t a) { return (uint32_t)((kg & 1) * L7_REGION) + ((((uint32_t)(kg >> 1)) ^ ((a >> 2) & 3u)) << 4); };
+    uint32_t fa[SPLIT ? 1 : 9], fs[SPLIT ? 1 : 9];
+    if constexpr (!SPLIT) {
 #pragma unroll
-    for (int tap = 0; tap < 9; tap++) {
-        const int dy = tap / 3, dx = tap - dy * 3;
-        const uint32_t a = (uint32_t)((2 + w + dy) * L7_PITCH + m + dx);
-        fa[tap] = a;
-        fs[tap] = (uint32_t)((kg & 1) * L7_REGION) + ((((uint32_t)(kg >> 1)) ^ ((a >> 2) & 3u)) << 4);
+        for (int tap = 0; tap < 9; tap++) {
+            fa[tap] = frag_a(tap);
+            fs[tap] = frag_s(fa[tap]);
+        }
     }
-    wait_vmcnt<5 * (L7_AHEAD - 1)>();
-    block_barrier();
+    if constexpr (SPLIT) {
+        if (loader) {
+            // ---- the loader wave: a step's row requests, their landing, the step's barrier; nothing else ----------------------
+            wait_vmcnt<0>();
+            block_barrier();
+            for (int s = s_begin; s < s_end; s++) {
+#pragma unroll
+                for (int vw = 0; vw < 4; vw++)
+                    l7_load_rows<5>(patch, scratch, in_img, in_img_bytes, vw, lane, L7_STEP_PIECES, ynext, 0, iy_max, pnext, X0, IW, tm);
+                ynext += L7_ROWS;
+                wait_vmcnt<0>();     // the next step's rows have landed ...
+                block_barrier();     // ... and the consumers are done with this step's
+                pnext += L7_STEP_PIECES;
+                pnext = pnext >= L7_RING_PIECES ? pnext - L7_RING_PIECES : pnext;
+            }
+            return;
+        }
+        block_barrier();             // consumers: the loader's prologue has landed
+    } else {
+        wait_vmcnt<5 * (L7_AHEAD - 1)>();
+        block_barrier();
+    }
 
     int base = 0;                          // (144 t) mod ring: ring slot of window row 4t, column 0
 #ifdef SICN_EXP_L7_STAMP
@@ -400,8 +440,10 @@ __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ 
     for (int s = s_begin; s < s_end; s++) {
         const int Y = 4 * s;               // first input row of this step
         // always issued (rows past the chunk are zero fill): the counted waits below rely on it
-        l7_load_rows<5>(patch, scratch, in_img, in_img_bytes, w, lane, L7_STEP_PIECES, ynext, 0, iy_max, pnext, X0, IW, tm);
-        ynext += L7_ROWS;
+        if constexpr (!SPLIT) {
+            l7_load_rows<5>(patch, scratch, in_img, in_img_bytes, w, lane, L7_STEP_PIECES, ynext, 0, iy_max, pnext, X0, IW, tm);
+            ynext += L7_ROWS;
+        }
         L7_T(0)   // the row requests (address arithmetic + issue)
 
 #ifdef SICN_EXP_L7_DMA_ONLY   // timing experiment (wrong bytes): the row requests, their counted wait and the barrier, nothing else
@@ -419,9 +461,10 @@ __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ 
         for (int tap = 0; tap < 9; tap++) {
 #pragma unroll
             for (int c = 0; c < 2; c++) {
-                uint32_t slot = (uint32_t)base + fa[tap] + 16u * c;
+                const uint32_t fa_t = SPLIT ? frag_a(tap) : fa[SPLIT ? 0 : tap], fs_t = SPLIT ? frag_s(fa_t) : fs[SPLIT ? 0 : tap];
+                uint32_t slot = (uint32_t)base + fa_t + 16u * c;
                 slot = min(slot, slot - (uint32_t)L7_RING_POS);   // one wrap at most
-                const uint32_t addr = slot * 64u + fs[tap];
+                const uint32_t addr = slot * 64u + fs_t;
 #if defined(SICN_EXP_L7_READS_ONLY)   // timing experiments (wrong bytes): the fragment reads without the MFMAs ...
                 const v4i p0 = *(const v4i *)(patch + addr);
                 const v4i p1 = *(const v4i *)(patch + (addr ^ 32u));
@@ -442,7 +485,7 @@ __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ 
         asm volatile("" :: "v"(acc[0]), "v"(acc[1]));
         L7_T(1)   // fragment reads + MFMAs issued
         // ---- epilogue ----------------------------------------------------------------------
-        const int gy = Y + w;
+        const int gy = Y + wr;
         if (fast_rows) {
             // stage [2 rows = py][64 pixels = 2*(16c+m)+px][3] and write the rows as dwords
 #pragma unroll
@@ -474,7 +517,10 @@ __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ 
 #if SICN_EXP_L7_STORE == 1
             wait_vmcnt<5 * (L7_AHEAD - 1)>();
 #else
-            wait_vmcnt<2 + 7 * (L7_AHEAD - 1)>();
+            if constexpr (SPLIT)
+                wait_vmcnt<6>();     // a consumer's only outstanding memory operations are its stores: keep at most three steps' worth
+            else
+                wait_vmcnt<2 + 7 * (L7_AHEAD - 1)>();
 #endif
         } else {
 #pragma unroll
@@ -508,6 +554,20 @@ __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ 
     }
 #endif
 }
+__global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int8_t *__restrict__ w_l7,
+                                                    const int8_t *__restrict__ bias, int IW, int IH, int OW, int OH, int steps_y, int y_chunks,
+                                                    int tiles_x, int n_images, int in_layout, int n_xcd)
+{
+    l7_body<false>(in, out, w_l7, bias, IW, IH, OW, OH, steps_y, y_chunks, tiles_x, n_images, in_layout, n_xcd);
+}
+// five waves: four consumers + the loader; three workgroups per CU = 15 waves, i.e. four on three of the SIMDs: 128 VGPRs at most
+__global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_l7s(
+    const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int8_t *__restrict__ w_l7, const int8_t *__restrict__ bias, int IW, int IH,
+    int OW, int OH, int steps_y, int y_chunks, int tiles_x, int n_images, int in_layout, int n_xcd)
+{
+    l7_body<true>(in, out, w_l7, bias, IW, IH, OW, OH, steps_y, y_chunks, tiles_x, n_images, in_layout, n_xcd);
+}
+
 #ifdef SICN_EXP_L7_STAMP
 extern "C" int sicn_debug_l7_stamps(unsigned long long *out8)   // reads and clears the sums
 {
@@ -553,10 +613,17 @@ hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
     // cut is the one that stays just under TWO workgroups per CU, 510 of 512; the 640 of round 2 was the middle of a flat region)
     const int y_chunks = l7_chunks(tiles_x, n_images, steps_y, o.strip_chunks, chip);
     const size_t lds = 2 * L7_REGION + 4 * L7_STAGE + 1024;
-    hipError_t e = hipFuncSetAttribute((const void *)k_l7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const bool split = o.l7_loader == 2;   // the loader-wave form (k_l7s): see l7_body; 0 / 1 = the four-wave kernel
+    const void *fn = split ? (const void *)k_l7s : (const void *)k_l7;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_l7, dim3(xcd_grid_size((long)tiles_x * y_chunks * n_images, chip.n_xcd)), dim3(256), lds, stream, in, out, w.d_w_l7,
-                       w.d_bias, g.IW, g.IH, g.OW, g.OH, steps_y, y_chunks, tiles_x, n_images, in_layout, chip.n_xcd);
+    const dim3 grid(xcd_grid_size((long)tiles_x * y_chunks * n_images, chip.n_xcd));
+    if (split)
+        hipLaunchKernelGGL(k_l7s, grid, dim3(320), lds, stream, in, out, w.d_w_l7, w.d_bias, g.IW, g.IH, g.OW, g.OH, steps_y, y_chunks,
+                           tiles_x, n_images, in_layout, chip.n_xcd);
+    else
+        hipLaunchKernelGGL(k_l7, grid, dim3(256), lds, stream, in, out, w.d_w_l7, w.d_bias, g.IW, g.IH, g.OW, g.OH, steps_y, y_chunks,
+                           tiles_x, n_images, in_layout, chip.n_xcd);
     return hipGetLastError();
 }
 

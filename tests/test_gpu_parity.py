@@ -826,3 +826,26 @@ def test_crop_nhwc_one_launch(api, shape):
     torch.cuda.synchronize()
     assert np.array_equal(d_dst.cpu().numpy(), src[:, :h, :w, :])
     assert _lib.lib().sicn_crop_nhwc(ctypes.c_void_p(d_src.data_ptr()), ctypes.c_void_p(d_dst.data_ptr()), n, hs, ws, hs + 1, w, c, None) == -22
+
+
+@pytest.mark.parametrize("chunks", [0, 1, 3])
+@pytest.mark.parametrize("case", [(128, 3, 8, 3, 70, 45, 1), (128, 3, 8, 3, 64, 32, 1), (128, 3, 8, 3, 1, 1, 1), (128, 3, 8, 3, 33, 7, 1), (128, 3, 8, 3, 96, 130, 1)])
+def test_layer7_loader_wave_form_matches_oracle(api, case, chunks):
+    """k_l7s (sicn_options.l7_loader = 2): a fifth wave issues all row requests of a step, four consumer waves
+    do reads + MFMAs + stores — same bytes as the oracle on ragged strips, single pixels, long strips cut into runs, batches."""
+    rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + chunks)
+    d = _mk_desc(*case)
+    W, b, words = _rand_params(rng, d)
+    x = rng.integers(0, 128, (2,) + d.in_shape, dtype=np.uint8)
+    x[1].reshape(-1)[::7] |= 0x80
+    got = _run_layer(api, d, words, b, x, l7_loader=2, strip_chunks=chunks)
+    for i in range(2):
+        assert np.array_equal(got[i], sicn_ref.deconv522_ref(x[i], W, b)), i
+
+
+def test_layer7_loader_wave_form_in_chain(api):
+    xin = _dev(_input("rng768")[None])
+    net = api.EightLayersNet(768, 512, options={"l7_loader": 2})
+    out, latent = net.forward(xin)
+    torch.cuda.synchronize()
+    assert _sha(out[0].cpu().numpy()) == HASHES["layers"]["rng768"][7]
