@@ -408,6 +408,13 @@ __global__ __launch_bounds__(256, 2) void k_deconv_p(const uint8_t *__restrict__
 #pragma unroll
         for (int r = 0; r < NC; r++) pbuf[0][r] = *(const v4i *)(lane_pix + ((r / Geo<TX>::XT) * PX + (r % Geo<TX>::XT) * 16) * 32);
     }
+    // Pass k's weight requests overwrite the ring slots of pass k's OWN tiles (prefetch distance = ring size): safe because every
+    // wave read those fragments in pass k - 1, in front of the barrier that ended it — except for pass 0, whose fragments are the
+    // reads just above.  Without this barrier a wave that runs ahead requests tiles 8 / 9 into slots 0 / 1 while a slower wave of
+    // the workgroup has not read tiles 0 / 1 yet.  Two workgroups per CU never showed it (a request takes longer to land than
+    // waves drift apart); the K-split kernels, whose smaller LDS footprint puts four to five workgroups on a CU, did: wrong bytes
+    // in phase 0, weight piece 1 (the piece the waves that run ahead write), timing dependent (round 4).
+    block_barrier();
     // one tap = PPT passes, the first one on pixel buffer PAR
     auto tap = [&](auto par_tag, int ph, int t, uint32_t toff, uint32_t toff_next) {
         constexpr int PAR = decltype(par_tag)::value;
@@ -686,6 +693,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_p(const uint8_t *__restrict__ i
 #pragma unroll
         for (int r = 0; r < NC; r++) pa[r] = *(const v4i *)(p0 + ((r / Geo<TX>::XT) * PX + (r % Geo<TX>::XT) * 16) * 32);
     }
+    block_barrier();   // pass 0's requests go into the slots just read: every wave must have read them first (see k_deconv_p)
     // VALU-initialised accumulators -> asm MFMA reading them as C: the wait states hipcc cannot know about
 #pragma unroll
     for (int c = 0; c < NC; c++)
@@ -776,15 +784,9 @@ static hipError_t launch_p(const LayerGeom &g, const sicn_weights &w, const uint
     }
     if constexpr (DECONV) {
         // the tap loop stays a loop where every CU holds two workgroups (full grids), and is unrolled on smaller ones (see
-        // SICN_DECONV_TAP_LOOP).  The K-split form (an option, never automatic) runs the LOOP: its unrolled build gave wrong bytes in
-        // phase 0 of a few tiles per launch — accumulator tiles j = 2, 3, i.e. the second 1-KiB piece of a weight tile, only when the
-        // previous kernel on the CU had left OTHER weights in LDS (layer 5 -> layer 6 in a chain; alone, the stale bytes are the
-        // right ones), timing dependent — while the loop form passes every repetition (gpurun_out r04 dbg*: 9 / 9 against 0 / 9).
-        // The cause was not found in the time given to an option that measures as a loss anyway (sicn_plan.h); the unsplit
-        // unrolled kernels share the prologue and pass the whole suite, fuzz runs included.  SICN_KSPLIT_UNROLLED=1 selects the
-        // failing build for whoever looks further.
-        static const bool ks_unrolled = getenv("SICN_KSPLIT_UNROLLED") != nullptr;
-        const bool rolled = KS == 1 ? (unsigned long long)grid.x * grid.y >= 2ull * (unsigned)chip.n_cu : !ks_unrolled;
+        // SICN_DECONV_TAP_LOOP); the K-split form (an option) is a small-grid form: unrolled.  (Its unrolled build was what exposed
+        // the missing barrier behind the prologue's fragment reads — see the comment there.)
+        const bool rolled = KS == 1 && (unsigned long long)grid.x * grid.y >= 2ull * (unsigned)chip.n_cu;
         auto go = [&](auto kern) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
@@ -792,7 +794,9 @@ static hipError_t launch_p(const LayerGeom &g, const sicn_weights &w, const uint
                                tiles_x * tiles_y, n_images, in_layout, out_layout, flags, chip.n_xcd, ka);
             return hipGetLastError();
         };
-        if (rolled) return go(&k_deconv_p<NQ, NT16, NTF, TX, PF, KS, true>);
+        if constexpr (KS == 1) {
+            if (rolled) return go(&k_deconv_p<NQ, NT16, NTF, TX, PF, KS, true>);
+        }
         return go(&k_deconv_p<NQ, NT16, NTF, TX, PF, KS, false>);
     } else {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_p<NQ, NT16, NTF, TX, PF, KS>),

@@ -511,7 +511,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define SICN_R(R) pa[R] = lds_read<((R >> 1) * PX + (R & 1) * 16) * 32>(p0); wa[R] = lds_read<R * 16 * 32>(ctx.lane_wt);
         SICN_R(0) SICN_R(1) SICN_R(2) SICN_R(3) SICN_R(4) SICN_R(5) SICN_R(6) SICN_R(7)
 #undef SICN_R
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // pass 0's requests overwrite the ring slots just read (prefetch distance = ring size): all four waves must have read them
+        // first — the passes' own barriers give that from pass 1 on (round 4: found in k_mfma16p.hip's K-split kernels)
+        block_barrier();
     }
     HandX h;
     h.soff = 0u;
@@ -803,7 +805,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define SICN_R(R) pa[R] = lds_read<((R >> 1) * PX + (R & 1) * 16) * 32>(p0); wa[R] = lds_read<R * 16 * 32>(ctx.lane_wt);
         SICN_R(0) SICN_R(1) SICN_R(2) SICN_R(3) SICN_R(4) SICN_R(5) SICN_R(6) SICN_R(7)
 #undef SICN_R
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // pass 0's requests overwrite the ring slots just read (prefetch distance = ring size): all four waves must have read them
+        // first — the passes' own barriers give that from pass 1 on (round 4: found in k_mfma16p.hip's K-split kernels)
+        block_barrier();
     }
     HandX h;
     h.soff = 0u;
