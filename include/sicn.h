@@ -139,7 +139,7 @@ int sicn_debug_plan(const sicn_layer_desc *desc, int n_images, const sicn_option
 long long sicn_debug_xcd_item(long long block, long long n_items, int n_xcd);
 int sicn_validate_desc(const sicn_layer_desc *desc); /* pure host check, no GPU needed         */
 /* Fills *opt with the library defaults (= all zero, overridden by the SICN_MFMA_SHAPE, SICN_TILE_X,
- * SICN_STRIP_CHUNKS, SICN_NO_PHASE_LAYOUT, SICN_SPLIT_N, SICN_SPLIT_K, SICN_WAVE_TILE, SICN_PREFETCH, SICN_FORCE_GENERIC environment
+ * SICN_STRIP_CHUNKS, SICN_NO_PHASE_LAYOUT, SICN_SPLIT_N, SICN_SPLIT_K, SICN_L7_LOADER, SICN_WAVE_TILE, SICN_PREFETCH, SICN_FORCE_GENERIC environment
  * variables as they were when the library was loaded; out-of-range values are ignored with one warning on stderr). */
 void sicn_options_init(sicn_options *opt);
 
