@@ -9,6 +9,8 @@
 // Both follow the closed forms of SURVEY.md §8(a) a8/a9 (bit-exact, wrap mod 256, relu7).
 #include <cstdlib>
 
+#include <algorithm>
+
 #include "k_common.hpp"
 
 namespace sicn {
@@ -38,6 +40,10 @@ constexpr int L0_RAW_BYTES = (L0_RAW_ROWS * L0_RAW_DW * 4 + 12 + 255) / 256 * 25
 // bytes into dwords 3g .. 3g+3 of the raw row (sh = byte phase of the row's first dword),
 // re-aligned in registers; pixels outside the image become 0 (the raw row holds the neighbouring
 // row's bytes there).  `raw` points at the raw row of patch row 0.
+// ASM_STORE (k_l0p): the patch store is an asm statement.  With LDS-DMA in flight (the next run's raw rows) hipcc orders every LDS
+// store it knows about behind the pending DMA with an s_waitcnt vmcnt(0) — which is also a wait for the tile's output stores; an
+// asm store it does not track, and the barrier that publishes the patch waits for lgkmcnt(0) anyway.
+template <bool ASM_STORE = false>
 __device__ __forceinline__ void l0_expand(const uint8_t *raw, uint8_t *patch, int img_byte0, int quad, int Y0, int X0,
                                           int IW, int IH)
 {
@@ -56,7 +62,12 @@ __device__ __forceinline__ void l0_expand(const uint8_t *raw, uint8_t *patch, in
     v.y = (row_ok && ix0 + 1 >= 0 && ix0 + 1 < IW) ? (__builtin_amdgcn_alignbyte(w1, w0, 3) & 0xFFFFFFu) : 0u;
     v.z = (row_ok && ix0 + 2 >= 0 && ix0 + 2 < IW) ? (__builtin_amdgcn_alignbyte(w2, w1, 2) & 0xFFFFFFu) : 0u;
     v.w = (row_ok && ix0 + 3 >= 0 && ix0 + 3 < IW) ? (w2 >> 8) : 0u;
-    *(uint4 *)(patch + quad * 16) = v;
+    if constexpr (ASM_STORE) {
+        const uint32_t a = (uint32_t)(uintptr_t)LDS_PTR(patch + quad * 16);
+        const v4i d = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+        asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(d) : "memory");
+    } else
+        *(uint4 *)(patch + quad * 16) = v;
 }
 
 // One workgroup = a vertical run of up to L0_CHUNK tiles of one 32-pixel strip.  The output stores
@@ -197,6 +208,222 @@ __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, u
     }
 }
 
+// ---- the PERSISTENT form of layer 0 (round 4) -------------------------------------------------------------------------------------
+// k_l0's cost model on 8 x 4K is 0.40 ms + 0.365 ms / (tiles per run): every workgroup pays a prologue — the burst that brings its
+// run's raw pixels, the weights and the bias into LDS, one memory latency, two barriers — that only the CU's other workgroup
+// covers.  Here two workgroups per CU each walk MANY runs of at most L0P_RUN tiles: the weights and the bias are loaded once,
+// and the raw pixels of the NEXT run arrive by LDS-DMA in a second buffer while the current run is computed.  The tile loop still
+// contains no wait that could catch a store: the one wait per run that the next run's pixels need is a COUNTED vmcnt (the
+// requests are older than the 8 stores per tile issued since), followed by one extra barrier per run.
+constexpr int L0P_RUN = 7;                                  // tiles per run: two raw buffers of 23.9 KB fit beside weights and patches
+constexpr int L0P_RAW_ROWS = 2 * L0_TY * L0P_RUN + 3;       // 115
+// a buffer holds WHOLE request instructions (64 lanes x 16 B): the lanes past the last row still write (zeros) — 512 bytes past a
+// buffer sized by rows alone, i.e. into the other buffer or, from the second one, past the workgroup's LDS and into the weights of
+// the CU's other workgroup (LDS-DMA is not held to the allocation: seen as wrong outputs at 2 x 4K, never with one workgroup per CU)
+constexpr int L0P_RAW_BYTES = (L0P_RAW_ROWS * (L0_RAW_DW / 4) + 63) / 64 * 1024;
+static_assert(L0P_RAW_BYTES >= L0P_RAW_ROWS * L0_RAW_DW * 4 + 12, "the last quad over-reads 3 dwords");
+static_assert(L0_RAW_BYTES >= (L0_RAW_ROWS * L0_RAW_DW + 63) / 64 * 256, "k_l0: whole request instructions fit the raw buffer");
+// one kernel row's MFMA operands of k_l0p: NTJ weight fragments and the pixel fragments of the wave's two output rows
+template <int NTJ>
+struct L0pFrag {
+    v4i wf[NTJ], pf[2];
+    template <int KY>
+    __device__ __forceinline__ void request(uint32_t wl_addr, const uint32_t (&wrow)[NTJ], uint32_t patch_addr)
+    {
+#pragma unroll
+        for (int j = 0; j < NTJ; j++)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[j]) : "v"(wl_addr + wrow[j]), "n"(KY * NTJ * 32 * KSTEP) : "memory");
+        // 8-byte aligned: two qwords; row 2 (2 w + i) + ky of the patch
+        asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(pf[0]) : "v"(patch_addr), "n"(KY * L0_PITCH / 8), "n"(KY * L0_PITCH / 8 + 1) : "memory");
+        asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(pf[1]) : "v"(patch_addr), "n"((KY + 2) * L0_PITCH / 8), "n"((KY + 2) * L0_PITCH / 8 + 1) : "memory");
+    }
+    template <int YOUNGER>
+    __device__ __forceinline__ void wait()
+    {
+        static_assert(NTJ == 4, "the operand list below names four weight fragments");
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(pf[0]), "+v"(pf[1]) : "n"(YOUNGER) : "memory");
+    }
+    __device__ __forceinline__ void mfma(v16i (&acc)[2][NTJ]) const
+    {
+#pragma unroll
+        for (int j = 0; j < NTJ; j++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[j], pf[i], acc[i][j], 0, 0, 0);
+    }
+};
+static_assert((L0_PITCH % 8) == 0 && (6 * L0_PITCH / 8 + 1) < 256, "ds_read2_b64 offsets are 8-bit counts of qwords");
+
+template <int NTJ>
+__global__ __launch_bounds__(256, 2) void k_l0p(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int8_t *__restrict__ w_l0,
+                                                const int8_t *__restrict__ bias, int IW, int IH, int OW, int OH, int tiles_x, int tiles_y,
+                                                int runs_y, int n_images, int out_layout, uint32_t act_floor)
+{
+    constexpr int COUT = NTJ * 32;
+    constexpr int TB = COUT * KSTEP;
+    constexpr int WBYTES = 5 * TB;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *wl = smem;
+    uint8_t *patch0 = smem + WBYTES;                  // two patches of L0_PATCH bytes
+    uint8_t *bias_lds = patch0 + 2 * L0_PATCH;
+    uint8_t *raw0 = bias_lds + 128;                   // two raw buffers of L0P_RAW_BYTES
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, kh = lane >> 5;
+    const int total_runs = tiles_x * runs_y * n_images;
+    int run = (int)blockIdx.x;
+    if (run >= total_runs) return;   // before any LDS-DMA is issued
+
+    const int im_bytes = IH * IW * 3;
+    const int tensor_bytes4 = (n_images * im_bytes + 3) & ~3;
+    const TensorMap om = tensor_map(out_layout, COUT, OW, OH);
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, tensor_bytes4, 0x00020000);
+
+    struct Run { int img, X0, ty_begin, ty_end, img_byte0; };
+    auto locate = [&](int r) {   // strips fastest: neighbouring workgroups read neighbouring columns of the same input rows
+        const int img = r / (tiles_x * runs_y), rem = r - img * (tiles_x * runs_y), ry = rem / tiles_x, bx = rem - ry * tiles_x;
+        const int tb = ry * L0P_RUN;
+        return Run{img, bx * TILE_X, tb, min(tiles_y, tb + L0P_RUN), img * im_bytes};
+    };
+    // the raw rows 2 Y - 2 .. of a run, 52 dwords each from the dword holding pixel 2 X0 - 2 (the image k_l0 keeps), moved SIXTEEN
+    // bytes per lane: 13 units per row, lane l of instruction k fetches unit 64 k + l.  (Not only a quarter of the requests: hipcc
+    // tracks the 4-byte `buffer_load_dword .. lds` as a pending LDS write and put an s_waitcnt vmcnt(0) — i.e. a wait for the tile's
+    // STORES — in front of every LDS access of the tile loop; the 16-byte form it leaves alone, as in the other kernels.)
+    // Rows outside the image read 0.  A unit is never dropped for a negative offset: the only row that starts before the tensor
+    // is row 0 of image 0 in strip 0 (offset -8: two dwords of padding, then pixels 0 .. 2) — its first unit is fetched from
+    // offset 0 into the slots 8 bytes on... which LDS-DMA cannot do (a lane's destination is fixed), so that one unit is zero-filled
+    // here and patched by two ordinary dword loads in the prologue of the workgroup that owns run 0 (always its first run).
+    constexpr int UNITS = L0_RAW_DW / 4;   // 13
+    static_assert(L0_RAW_DW % 4 == 0, "a raw row is a whole number of 16-byte units");
+    auto request_raw = [&](const Run &r, uint8_t *raw) {
+        const int rows = 2 * L0_TY * (r.ty_end - r.ty_begin) + 3;
+        const int n_instr = (rows * UNITS + 63) / 64;
+        for (int k = w; k < n_instr; k += 4) {
+            const int idx = 64 * k + lane;
+            const int rr = idx / UNITS, c = idx - rr * UNITS;
+            const int iy = 2 * L0_TY * r.ty_begin - 2 + rr;
+            const int o = ((r.img_byte0 + (iy * IW + 2 * r.X0 - 2) * 3) & ~3) + 16 * c;
+            const bool ok = rr < rows && iy >= 0 && iy < IH && o >= 0;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(raw + k * 1024), 16, ok ? (uint32_t)o : OOB, 0, 0, 0);
+        }
+    };
+
+    Run cur = locate(run);
+    request_raw(cur, raw0);
+    for (int piece = w; piece < WBYTES / 1024; piece += 4)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(w_l0 + piece * 1024 + lane * 16), LDS_PTR(wl + piece * 1024), 16, 0, 0);
+    if (tid < COUT / 4) ((uint32_t *)bias_lds)[tid] = ((const uint32_t *)bias)[tid];
+    uint32_t wrow[NTJ];
+#pragma unroll
+    for (int j = 0; j < NTJ; j++) wrow[j] = (uint32_t)((j * 32 + m) * 32 + ((kh ^ ((m >> 3) & 1)) << 4));
+    // the one unit that starts before the tensor (see request_raw): raw row 2 (input row 0) of run 0, bytes 8 .. 15 = tensor bytes 0 .. 7
+    uint32_t corner = 0;
+    const bool patch_corner = run == 0 && tid < 2;
+    if (patch_corner) corner = ((const uint32_t *)in)[tid];   // the tensor holds at least one pixel row of >= 1 pixel... and 8 bytes? checked by the launcher
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), the builtin: hipcc then knows nothing is pending (see k_l0)
+    block_barrier();
+    if (patch_corner) ((uint32_t *)(raw0 + 2 * L0_RAW_DW * 4 + 8))[tid] = corner;
+    block_barrier();
+    l0_expand(raw0, patch0, cur.img_byte0, tid, cur.ty_begin * L0_TY, cur.X0, IW, IH);
+    l0_expand(raw0, patch0, cur.img_byte0, tid + 256, cur.ty_begin * L0_TY, cur.X0, IW, IH);
+    block_barrier();
+
+    int buf = 0, rbuf = 0;
+    for (;;) {
+        const int next_run = run + (int)gridDim.x;
+        const bool has_next = next_run < total_runs;
+        Run nxt = cur;
+        uint8_t *raw = raw0 + rbuf * L0P_RAW_BYTES, *raw_next = raw0 + (rbuf ^ 1) * L0P_RAW_BYTES;
+        if (has_next) {   // the next run's pixels: in flight under this whole run (the buffer was free since the previous run ended)
+            nxt = locate(next_run);
+            request_raw(nxt, raw_next);
+        }
+        uint8_t *out_img = out + (size_t)cur.img * OH * OW * COUT;
+        __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)out_img, 0, OH * OW * COUT, 0x00020000);
+        const int n_tiles = cur.ty_end - cur.ty_begin;
+        for (int t = 0; t < n_tiles; t++, buf ^= 1) {
+            const int Y0 = (cur.ty_begin + t) * L0_TY;
+            const uint8_t *patch = patch0 + buf * L0_PATCH;
+            uint8_t *pnext = patch0 + (buf ^ 1) * L0_PATCH;
+            if (t + 1 < n_tiles) {   // pixels of the run's next tile -> the patch nobody reads in this iteration
+                const uint8_t *rsrc = raw + (t + 1) * (2 * L0_TY * L0_RAW_DW * 4);
+                l0_expand<true>(rsrc, pnext, cur.img_byte0, tid, Y0 + L0_TY, cur.X0, IW, IH);
+                l0_expand<true>(rsrc, pnext, cur.img_byte0, tid + 256, Y0 + L0_TY, cur.X0, IW, IH);
+            } else if (has_next) {
+                // the next run's first tile.  Its raw rows were requested before this run's first store: everything but the
+                // 8 (t) stores issued since has to have landed — counted, so no store is waited for — in every wave
+                switch (t) {
+                case 0: wait_vmcnt<0>(); break;
+                case 1: wait_vmcnt<8>(); break;
+                case 2: wait_vmcnt<16>(); break;
+                case 3: wait_vmcnt<24>(); break;
+                case 4: wait_vmcnt<32>(); break;
+                case 5: wait_vmcnt<40>(); break;
+                default: wait_vmcnt<48>(); break;
+                }
+                block_barrier();
+                l0_expand<true>(raw_next, pnext, nxt.img_byte0, tid, nxt.ty_begin * L0_TY, nxt.X0, IW, IH);
+                l0_expand<true>(raw_next, pnext, nxt.img_byte0, tid + 256, nxt.ty_begin * L0_TY, nxt.X0, IW, IH);
+            }
+
+            v16i acc[2][NTJ];
+#pragma unroll
+            for (int j = 0; j < NTJ; j++) {
+                const v4i b4 = *(const v4i *)(bias_lds + j * 32 + 16 * kh);
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int bv = (int)(int8_t)((uint32_t)b4[r >> 2] >> (8 * (r & 3)));
+                    acc[0][j][r] = bv;
+                    acc[1][j][r] = bv;
+                }
+            }
+            // The fragment reads are asm (a read hipcc can see is ordered behind the pending LDS-DMA with a vmcnt(0), i.e. behind the
+            // tile's stores), so their pipeline is written out: kernel row ky + 1 is requested before the MFMAs of row ky, and each
+            // wait NAMES the registers it releases — an MFMA depends on those, not on a bare s_waitcnt statement (the first build had
+            // one, hipcc moved the MFMAs in front of it: a quarter of all outputs wrong).  LDS operations hipcc issues itself in
+            // between can only make the counted waits stricter.
+            const uint32_t wa = (uint32_t)(uintptr_t)LDS_PTR(wl), pa = (uint32_t)(uintptr_t)LDS_PTR(patch + 4 * w * L0_PITCH + 8 * m + 16 * kh);
+            L0pFrag<NTJ> fa, fb;
+            fa.template request<0>(wa, wrow, pa);
+            fb.template request<1>(wa, wrow, pa);
+            fa.template wait<NTJ + 2>();
+            fa.mfma(acc);
+            fa.template request<2>(wa, wrow, pa);
+            fb.template wait<NTJ + 2>();
+            fb.mfma(acc);
+            fb.template request<3>(wa, wrow, pa);
+            fa.template wait<NTJ + 2>();
+            fa.mfma(acc);
+            fa.template request<4>(wa, wrow, pa);
+            fb.template wait<NTJ + 2>();
+            fb.mfma(acc);
+            fa.template wait<0>();
+            fa.mfma(acc);
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int gy = Y0 + 2 * w + i, gx = cur.X0 + m;
+                const bool ok = gy < OH && gx < OW;
+#pragma unroll
+                for (int j = 0; j < NTJ; j++) {
+                    const v16i a = acc[i][j];
+                    v4i v;
+                    v[0] = (int)pack4_relu7(a[0], a[1], a[2], a[3], act_floor & ACT_FLOOR_MASK);
+                    v[1] = (int)pack4_relu7(a[4], a[5], a[6], a[7], act_floor & ACT_FLOOR_MASK);
+                    v[2] = (int)pack4_relu7(a[8], a[9], a[10], a[11], act_floor & ACT_FLOOR_MASK);
+                    v[3] = (int)pack4_relu7(a[12], a[13], a[14], a[15], act_floor & ACT_FLOOR_MASK);
+                    const uint32_t off = ok ? tensor_offset(om, gy, gx, (uint32_t)j) + 16u * kh : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, ro, off, 0, 0);   // ALWAYS issued (out-of-image lanes: out of range): the counted wait relies on 8 per tile
+                }
+            }
+            block_barrier();  // next patch complete, this patch free (raw barrier: the stores stay in flight)
+        }
+        if (!has_next) break;
+        run = next_run;
+        cur = nxt;
+        rbuf ^= 1;
+    }
+}
+
 // Test hook: sicn_options.strip_chunks = n forces the number of vertical chunks a strip is cut into (the
 // default heuristic gives small images one step per workgroup, which never exercises the rolling window).
 
@@ -231,6 +458,24 @@ hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
     dim3 grid((unsigned)tiles_x, (unsigned)y_chunks, (unsigned)n_images);
     if ((size_t)g.IH * g.IW * 3 * (size_t)n_images + 4 >= (size_t)OOB) return hipErrorInvalidValue;
     if ((size_t)g.OH * g.OW * g.COUT >= (size_t)OOB) return hipErrorInvalidValue;   // buffer-descriptor stores
+    // the persistent form (k_l0p): sicn_options.l0_form = 2 only.  Measured on 8 x 4K (r04, A/B in one process): 0.481 ms against
+    // k_l0's 0.434 — the layer is bound by issue slots (40 MFMAs of 32 cycles + the packing per tile and wave), not by the prologue
+    // the persistent form removes; DESIGN.md §3.2.  Kept as a tested alternative.
+    const int runs_y = (tiles_y + L0P_RUN - 1) / L0P_RUN;
+    const long total_runs = (long)tiles_x * runs_y * n_images;
+    // (the corner patch of k_l0p reads the tensor's first 8 bytes: at least three pixels)
+    const bool persistent = o.l0_form == 2 && g.COUT == 128 && (size_t)g.IH * g.IW * n_images >= 3;
+    if (persistent) {
+        if (total_runs > 0x7fffffffL) return hipErrorInvalidValue;
+        const size_t lds = 5 * 128 * KSTEP + 2 * L0_PATCH + 128 + 2 * L0P_RAW_BYTES;
+        hipError_t e = hipFuncSetAttribute((const void *)k_l0p<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        long cap = o.persistent_grid > 0 ? o.persistent_grid : 2L * chip.n_cu;
+        const unsigned wgs = (unsigned)std::min<long>(cap < 1 ? 1 : cap, total_runs);
+        hipLaunchKernelGGL(k_l0p<4>, dim3(wgs), dim3(256), lds, stream, in, out, w.d_w_l0, w.d_bias, g.IW, g.IH, g.OW, g.OH, tiles_x, tiles_y,
+                           runs_y, n_images, out_layout, relu ? ACT_FLOOR_RELU : ACT_FLOOR_RAW);
+        return hipGetLastError();
+    }
     if (g.COUT == 128) {
         const size_t lds = 5 * 128 * KSTEP + 2 * L0_PATCH + 128 + L0_RAW_BYTES;
         hipError_t e = hipFuncSetAttribute((const void *)k_l0<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

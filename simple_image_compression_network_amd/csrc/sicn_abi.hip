@@ -41,6 +41,7 @@ const sicn_options &default_options()
         d.prefetch = env_int("SICN_PREFETCH");
         d.split_k = env_int("SICN_SPLIT_K");
         d.l7_loader = env_int("SICN_L7_LOADER");
+        d.l0_form = env_int("SICN_L0_FORM");
         // the same range checks a caller's struct gets (resolve_options): an out-of-range variable is ignored, loudly, once
         auto bad = [](const char *name, int32_t &v) {
             fprintf(stderr, "libsicn: ignoring out-of-range %s=%d\n", name, (int)v);
@@ -58,6 +59,7 @@ const sicn_options &default_options()
         if (d.prefetch < 0 || d.prefetch > 3) bad("SICN_PREFETCH", d.prefetch);
         if (d.split_k < 0 || d.split_k > 4) bad("SICN_SPLIT_K", d.split_k);
         if (d.l7_loader < 0 || d.l7_loader > 2) bad("SICN_L7_LOADER", d.l7_loader);
+        if (d.l0_form < 0 || d.l0_form > 2) bad("SICN_L0_FORM", d.l0_form);
         return d;
     }();
     return o;
@@ -115,7 +117,7 @@ static int resolve_options(const sicn_options *in, sicn_options *out)
     if (o.split_n < 0 || o.split_n > 4) return SICN_EINVAL;
     if (o.wave_tile != 0 && o.wave_tile != 64 && o.wave_tile != 128) return SICN_EINVAL;
     if (o.prefetch < 0 || o.prefetch > 3 || o.persistent_grid < 0) return SICN_EINVAL;
-    if (o.split_k < 0 || o.split_k > 4 || o.l7_loader < 0 || o.l7_loader > 2) return SICN_EINVAL;
+    if (o.split_k < 0 || o.split_k > 4 || o.l7_loader < 0 || o.l7_loader > 2 || o.l0_form < 0 || o.l0_form > 2) return SICN_EINVAL;
     *out = o;
     return SICN_OK;
 }

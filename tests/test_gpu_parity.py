@@ -849,3 +849,41 @@ def test_layer7_loader_wave_form_in_chain(api):
     out, latent = net.forward(xin)
     torch.cuda.synchronize()
     assert _sha(out[0].cpu().numpy()) == HASHES["layers"]["rng768"][7]
+
+
+@pytest.mark.parametrize("grid", [0, 1, 3, 8])
+@pytest.mark.parametrize("case", [(3, 128, 3, 8, 140, 150, 0), (3, 128, 3, 8, 64, 48, 0), (3, 128, 3, 8, 2, 2, 0), (3, 128, 3, 8, 70, 290, 0), (3, 128, 3, 8, 513, 31, 0)])
+def test_layer0_persistent_form_matches_oracle(api, case, grid):
+    """k_l0p (sicn_options.l0_form = 2): two workgroups per CU walk many runs of <= 7 tiles, the next run's raw pixels arriving by
+    LDS-DMA under the current one — forced here on small images with 1 / 3 / 8 workgroups so that every workgroup crosses run,
+    strip and image boundaries; pixels >= 128; the first unit of the tensor (the corner patched by ordinary loads) included."""
+    rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + grid)
+    d = _mk_desc(*case)
+    W, b, words = _rand_params(rng, d)
+    x = rng.integers(0, 256, (3,) + d.in_shape, dtype=np.uint8)
+    got = _run_layer(api, d, words, b, x, l0_form=2, persistent_grid=grid)
+    for i in range(3):
+        assert np.array_equal(got[i], sicn_ref.conv2d_ref(x[i], W, b)), i
+    assert np.array_equal(got, _run_layer(api, d, words, b, x, l0_form=1))
+
+
+def test_layer0_persistent_form_in_chain(api):
+    xin = _dev(np.stack([_input("rng768"), _input("ones768")]))
+    net = api.EightLayersNet(768, 512, options={"l0_form": 2, "persistent_grid": 16})
+    out, latent = net.forward(xin)
+    torch.cuda.synchronize()
+    for i, name in enumerate(("rng768", "ones768")):
+        assert _sha(out[i].cpu().numpy()) == HASHES["layers"][name][7]
+        assert _sha(latent[i].cpu().numpy()) == HASHES["layers"][name][3]
+
+
+def test_layer0_persistent_form_two_workgroups_per_cu(api):
+    """3 x 1080p = 900 runs: 512 workgroups, two on every CU, most with two runs.  (The first build of k_l0p sized its raw buffers
+    by rows, and the idle lanes of the last request instruction wrote zeros past the workgroup's LDS — into the weights of the
+    CU's other workgroup; invisible to every test that puts one workgroup on a CU.)"""
+    rng = np.random.default_rng(77)
+    d = _mk_desc(3, 128, 3, 8, 1920, 1080, 0)
+    _, b, words = _rand_params(rng, d)
+    x = rng.integers(0, 256, (3,) + d.in_shape, dtype=np.uint8)
+    a = _run_layer(api, d, words, b, x, l0_form=2)
+    assert np.array_equal(a, _run_layer(api, d, words, b, x, l0_form=1))
