@@ -111,7 +111,9 @@ typedef struct sicn_options {
                              /*    loader-wave form k_l7s (a fifth wave issues all row requests)        */
     int32_t l0_form;         /* layer 0: 0 / 1: one workgroup per run of tiles (k_l0); 2: the persistent kernel k_l0p (two      */
                              /*    workgroups per CU walk many runs, persistent_grid caps them; measured 11 % slower) */
-    int32_t reserved[3];
+    int32_t gdn_fuse;        /* a layer with a sicn_gdn: 0: layer and activation in one kernel where that exists (layer 0 with  */
+                             /*    128 channels, k_l0g); 1: always the layer kernel followed by k_gdn in place                   */
+    int32_t reserved[2];
 } sicn_options;
 
 typedef struct sicn_weights sicn_weights; /* one layer's weights+bias, resident on the device  */
@@ -141,7 +143,7 @@ int sicn_debug_plan(const sicn_layer_desc *desc, int n_images, const sicn_option
 long long sicn_debug_xcd_item(long long block, long long n_items, int n_xcd);
 int sicn_validate_desc(const sicn_layer_desc *desc); /* pure host check, no GPU needed         */
 /* Fills *opt with the library defaults (= all zero, overridden by the SICN_MFMA_SHAPE, SICN_TILE_X,
- * SICN_STRIP_CHUNKS, SICN_NO_PHASE_LAYOUT, SICN_SPLIT_N, SICN_SPLIT_K, SICN_L7_LOADER, SICN_L0_FORM, SICN_WAVE_TILE, SICN_PREFETCH, SICN_FORCE_GENERIC environment
+ * SICN_STRIP_CHUNKS, SICN_NO_PHASE_LAYOUT, SICN_SPLIT_N, SICN_SPLIT_K, SICN_L7_LOADER, SICN_L0_FORM, SICN_GDN_FUSE, SICN_WAVE_TILE, SICN_PREFETCH, SICN_FORCE_GENERIC environment
  * variables as they were when the library was loaded; out-of-range values are ignored with one warning on stderr). */
 void sicn_options_init(sicn_options *opt);
 

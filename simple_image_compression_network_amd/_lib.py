@@ -19,7 +19,7 @@ _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 class COptions(ctypes.Structure):
     """ctypes image of `sicn_options` (include/sicn.h): kernel-selection knobs, passed by value per call / per net."""
     _fields_ = [(n, ctypes.c_int32) for n in ("struct_bytes", "force_generic", "mfma_shape", "tile_x", "strip_chunks",
-                                              "no_phase_layout", "split_n", "wave_tile", "prefetch", "persistent_grid", "split_k", "l7_loader", "l0_form")] + [("reserved", ctypes.c_int32 * 3)]
+                                              "no_phase_layout", "split_n", "wave_tile", "prefetch", "persistent_grid", "split_k", "l7_loader", "l0_form", "gdn_fuse")] + [("reserved", ctypes.c_int32 * 2)]
 
 
 def make_options(**kw) -> "COptions":

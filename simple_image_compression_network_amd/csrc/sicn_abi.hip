@@ -42,6 +42,7 @@ const sicn_options &default_options()
         d.split_k = env_int("SICN_SPLIT_K");
         d.l7_loader = env_int("SICN_L7_LOADER");
         d.l0_form = env_int("SICN_L0_FORM");
+        d.gdn_fuse = env_int("SICN_GDN_FUSE");
         // the same range checks a caller's struct gets (resolve_options): an out-of-range variable is ignored, loudly, once
         auto bad = [](const char *name, int32_t &v) {
             fprintf(stderr, "libsicn: ignoring out-of-range %s=%d\n", name, (int)v);
@@ -60,6 +61,7 @@ const sicn_options &default_options()
         if (d.split_k < 0 || d.split_k > 4) bad("SICN_SPLIT_K", d.split_k);
         if (d.l7_loader < 0 || d.l7_loader > 2) bad("SICN_L7_LOADER", d.l7_loader);
         if (d.l0_form < 0 || d.l0_form > 2) bad("SICN_L0_FORM", d.l0_form);
+        if (d.gdn_fuse < 0 || d.gdn_fuse > 1) bad("SICN_GDN_FUSE", d.gdn_fuse);
         return d;
     }();
     return o;
@@ -117,7 +119,9 @@ static int resolve_options(const sicn_options *in, sicn_options *out)
     if (o.split_n < 0 || o.split_n > 4) return SICN_EINVAL;
     if (o.wave_tile != 0 && o.wave_tile != 64 && o.wave_tile != 128) return SICN_EINVAL;
     if (o.prefetch < 0 || o.prefetch > 3 || o.persistent_grid < 0) return SICN_EINVAL;
-    if (o.split_k < 0 || o.split_k > 4 || o.l7_loader < 0 || o.l7_loader > 2 || o.l0_form < 0 || o.l0_form > 2) return SICN_EINVAL;
+    if (o.split_k < 0 || o.split_k > 4 || o.l7_loader < 0 || o.l7_loader > 2 || o.l0_form < 0 || o.l0_form > 2 || o.gdn_fuse < 0 ||
+        o.gdn_fuse > 1)
+        return SICN_EINVAL;
     *out = o;
     return SICN_OK;
 }
@@ -221,6 +225,7 @@ extern "C" void sicn_weights_free(sicn_weights *w)
     if (w->d_w_mfma16) (void)hipFree(w->d_w_mfma16);
     if (w->d_w_mfma16x) (void)hipFree(w->d_w_mfma16x);
     if (w->d_w_l0) (void)hipFree(w->d_w_l0);
+    if (w->d_w_l0g) (void)hipFree(w->d_w_l0g);
     if (w->d_w_l7) (void)hipFree(w->d_w_l7);
     delete w;
 }
@@ -296,6 +301,11 @@ extern "C" int sicn_weights_from_finn_tiles(const sicn_layer_desc *d, const void
             std::vector<int8_t> s(l0_bytes(cout));
             pack_l0(w_okc.data(), cout, s.data());
             ok = upload(s.data(), s.size(), &w->d_w_l0);
+            if (ok && cout == 128) {   // the image of the kernel that applies a GDN before its store
+                std::vector<int8_t> sg(l0g_bytes());
+                pack_l0g(w_okc.data(), sg.data());
+                ok = upload(sg.data(), sg.size(), &w->d_w_l0g);
+            }
         }
         if (ok && d->transposed && cin == 128 && cout == 3) {
             std::vector<int8_t> s(l7_bytes(cin));
@@ -356,7 +366,15 @@ static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint
     if ((rc = chip_geom(&chip)) != SICN_OK) return rc;   // no device, or not a gfx950 one
     hipError_t e;
     switch (layer_kernel(*d, o, gdn != nullptr)) {
-    case KK_L0_RGB: e = launch_l0(g, *w, in, out, n_images, stream, out_layout, o, chip, relu); break;
+    case KK_L0_RGB:
+        // layer 0 + activation in one kernel where it exists (128 channels): the pre-activation tensor never reaches HBM
+        if (gdn && o.gdn_fuse == 0 && w->d_w_l0g && gdn->d_gamma_mfma && gdn->channels == 128) {
+            e = launch_l0_gdn(g, *w, *gdn, in, out, n_images, stream, out_layout, o, chip);
+            gdn = nullptr;
+            break;
+        }
+        e = launch_l0(g, *w, in, out, n_images, stream, out_layout, o, chip, relu);
+        break;
     case KK_L7_RGB: e = launch_l7(g, *w, in, out, n_images, stream, in_layout, o, chip); break;
     case KK_MFMA_CONV:
     case KK_MFMA_DECONV:

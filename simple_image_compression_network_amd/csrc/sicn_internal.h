@@ -47,6 +47,7 @@ struct sicn_weights {
     int8_t *d_bias_sigma;  // [cout] bias in sigma order == natural order (kept for clarity)
     // layer-0 (RGB -> cout) and layer-7 (cin -> RGB) layouts, or nullptr
     int8_t *d_w_l0;
+    int8_t *d_w_l0g;       // layer 0, 128 channels: the A-operand image of the kernel that applies a GDN before its store (k_l0g.hip)
     int8_t *d_w_l7;
 };
 
@@ -132,6 +133,8 @@ void pack_mfma16_stream(const int8_t *w_okc, int cin, int cout, int transposed, 
 
 size_t l0_bytes(int cout);
 void pack_l0(const int8_t *w_okc, int cout, int8_t *dst);
+size_t l0g_bytes();
+void pack_l0g(const int8_t *w_okc, int8_t *dst);   // cout = 128
 size_t l7_bytes(int cin);
 void pack_l7(const int8_t *w_okc, int cin, int8_t *dst);
 

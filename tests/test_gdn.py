@@ -268,3 +268,49 @@ def test_gpu_gdn_net_all_internal_layouts(options):
             if l == 3:
                 assert np.array_equal(lat[i], a), "latent"
         assert np.array_equal(out[i], a), "reconstruction"
+
+
+@gpu
+@pytest.mark.parametrize("size", [(70, 38), (5, 3), (129, 17), (64, 2), (1, 1), (140, 150), (513, 31), (70, 290)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gpu_layer0_with_gdn_in_one_kernel_equals_oracle(size, inverse):
+    """k_l0g (round 4): layer 0 and its GDN / IGDN in one kernel — the pre-activation tensor stays in registers.  Sizes: sub-tile,
+    odd, one row / one pixel, several 32-column strips, runs of 4 tiles with a shorter last run (70 x 290: 19 tiles), pixels
+    >= 128; three images.  Held to the oracle AND to the two-kernel path (sicn_options.gdn_fuse = 1), with the default cut and
+    with the strips forced into 1 / 3 / 5 runs."""
+    import torch
+    from simple_image_compression_network_amd import api
+    rng = np.random.default_rng(abs(hash(size)) % (1 << 31) + inverse)
+    d = _mk_desc(3, 128, 3, 8, size[0], size[1], 0)
+    W = rng.integers(-8, 8, (128, 5, 5, 3)).astype(np.int8)
+    b = rng.integers(-128, 128, 128).astype(np.int8)
+    words = sicn_ref.pack_finn_tiles(W, d.SIMD, d.PE)
+    x = rng.integers(0, 256, (3,) + d.in_shape, dtype=np.uint8)
+    beta, gamma = _params(rng, 128)
+    g = api.GDN(beta, gamma, inverse, 12)
+    fpw = api.FixedPointWeights(d.SIMD, 4, d.PE, d.W_TILES, words)
+    xd = torch.from_numpy(x).cuda()
+    got = api.conv2d(d, fpw, b, xd, None, 3, gdn=g).cpu().numpy()
+    for i in range(3):
+        pre = sicn_ref.layer_preact_ref(x[i], W, b, 0)
+        assert np.array_equal(got[i], c_oracle.gdn(pre, beta, gamma, inverse, 12)), i
+    assert np.array_equal(got, api.conv2d(d, fpw, b, xd, None, 3, gdn=g, options={"gdn_fuse": 1}).cpu().numpy())
+    for chunks in (1, 3, 5):
+        assert np.array_equal(got, api.conv2d(d, fpw, b, xd, None, 3, gdn=g, options={"strip_chunks": chunks}).cpu().numpy()), chunks
+
+
+@gpu
+def test_gpu_layer0_with_gdn_in_one_kernel_at_1080p():
+    """Two workgroups on every CU (2 x 1080p = 4080 workgroups of 512 threads), the layouts of a chain: against the two-kernel path."""
+    import torch
+    from simple_image_compression_network_amd import api
+    rng = np.random.default_rng(31)
+    d = _mk_desc(3, 128, 3, 8, 1920, 1080, 0)
+    W = rng.integers(-8, 8, (128, 5, 5, 3)).astype(np.int8)
+    b = rng.integers(-128, 128, 128).astype(np.int8)
+    fpw = api.FixedPointWeights(d.SIMD, 4, d.PE, d.W_TILES, sicn_ref.pack_finn_tiles(W, d.SIMD, d.PE))
+    xd = torch.from_numpy(rng.integers(0, 256, (2,) + d.in_shape, dtype=np.uint8)).cuda()
+    beta, gamma = _params(rng, 128)
+    g = api.GDN(beta, gamma, False, 12)
+    a = api.conv2d(d, fpw, b, xd, None, 2, gdn=g)
+    assert torch.equal(a, api.conv2d(d, fpw, b, xd, None, 2, gdn=g, options={"gdn_fuse": 1}))
