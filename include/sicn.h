@@ -111,8 +111,10 @@ typedef struct sicn_options {
                              /*    loader-wave form k_l7s (a fifth wave issues all row requests)        */
     int32_t l0_form;         /* layer 0: 0 / 1: one workgroup per run of tiles (k_l0); 2: the persistent kernel k_l0p (two      */
                              /*    workgroups per CU walk many runs, persistent_grid caps them; measured 11 % slower) */
-    int32_t gdn_fuse;        /* a layer with a sicn_gdn: 0: layer and activation in one kernel where that exists (layer 0 with  */
-                             /*    128 channels, k_l0g); 1: always the layer kernel followed by k_gdn in place                   */
+    int32_t gdn_fuse;        /* layers with a sicn_gdn: 0: layer 0 with 128 channels applies its activation itself, before its  */
+                             /*    one store (k_l0g: - 0.35 ms per 8 x 4K step); 1: never (layer kernel, then k_gdn in place);   */
+                             /*    2: 0 + the 128 -> RGB layer of a chain applies the activation of the layer before it on the   */
+                             /*    way in (k_l7g: measured no faster than k_gdn + k_l7)                            */
     int32_t reserved[2];
 } sicn_options;
 

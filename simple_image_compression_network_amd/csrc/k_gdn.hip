@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, 4) void k_gdn(uint8_t *__restrict__ data, cons
                                                 const uint32_t *__restrict__ beta, long long image_bytes, uint32_t n_pos,
                                                 GdnMap map, int sh, int blocks_per_image)
 {
-    constexpr int C = 64 * NJ, NT = C / 16;
+    constexpr int C = 64 * NJ;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *gl = smem;                              // gamma image: [J][j][kg][rho][16 B]
     uint32_t *bl = (uint32_t *)(smem + C * C);       // beta in natural channel order

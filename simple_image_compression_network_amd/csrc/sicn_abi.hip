@@ -61,7 +61,7 @@ const sicn_options &default_options()
         if (d.split_k < 0 || d.split_k > 4) bad("SICN_SPLIT_K", d.split_k);
         if (d.l7_loader < 0 || d.l7_loader > 2) bad("SICN_L7_LOADER", d.l7_loader);
         if (d.l0_form < 0 || d.l0_form > 2) bad("SICN_L0_FORM", d.l0_form);
-        if (d.gdn_fuse < 0 || d.gdn_fuse > 1) bad("SICN_GDN_FUSE", d.gdn_fuse);
+        if (d.gdn_fuse < 0 || d.gdn_fuse > 2) bad("SICN_GDN_FUSE", d.gdn_fuse);
         return d;
     }();
     return o;
@@ -120,7 +120,7 @@ static int resolve_options(const sicn_options *in, sicn_options *out)
     if (o.wave_tile != 0 && o.wave_tile != 64 && o.wave_tile != 128) return SICN_EINVAL;
     if (o.prefetch < 0 || o.prefetch > 3 || o.persistent_grid < 0) return SICN_EINVAL;
     if (o.split_k < 0 || o.split_k > 4 || o.l7_loader < 0 || o.l7_loader > 2 || o.l0_form < 0 || o.l0_form > 2 || o.gdn_fuse < 0 ||
-        o.gdn_fuse > 1)
+        o.gdn_fuse > 2)
         return SICN_EINVAL;
     *out = o;
     return SICN_OK;
@@ -347,10 +347,12 @@ static int link_layout(const sicn_layer_desc &p, const sicn_layer_desc &c, const
 }
 
 // gdn != nullptr: the layer stores its lanes BEFORE the sign-bit ReLU and the GDN / IGDN kernel then rewrites them in
-// place, in whatever layout the layer wrote (include/sicn_gdn.h; extension beyond the reference).
+// place, in whatever layout the layer wrote (include/sicn_gdn.h; extension beyond the reference).  defer_gdn: the rewrite is
+// left to the NEXT layer of a chain, which gets this layer's activation as its in_gdn (sicn_net_forward decides).
 static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint8_t *in, uint8_t *out,
                      int n_images, hipStream_t stream, int want_transposed, const sicn_options &o, int in_layout = 0,
-                     int out_layout = 0, const sicn_gdn *gdn = nullptr, const KSplitScratch *ks = nullptr)
+                     int out_layout = 0, const sicn_gdn *gdn = nullptr, const KSplitScratch *ks = nullptr, bool defer_gdn = false,
+                     const sicn_gdn *in_gdn = nullptr)
 {
     int rc = sicn_validate_desc(d);
     if (rc) return rc;
@@ -368,14 +370,18 @@ static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint
     switch (layer_kernel(*d, o, gdn != nullptr)) {
     case KK_L0_RGB:
         // layer 0 + activation in one kernel where it exists (128 channels): the pre-activation tensor never reaches HBM
-        if (gdn && o.gdn_fuse == 0 && w->d_w_l0g && gdn->d_gamma_mfma && gdn->channels == 128) {
+        if (gdn && o.gdn_fuse != 1 && w->d_w_l0g && gdn->d_gamma_mfma && gdn->channels == 128) {
             e = launch_l0_gdn(g, *w, *gdn, in, out, n_images, stream, out_layout, o, chip);
             gdn = nullptr;
             break;
         }
         e = launch_l0(g, *w, in, out, n_images, stream, out_layout, o, chip, relu);
         break;
-    case KK_L7_RGB: e = launch_l7(g, *w, in, out, n_images, stream, in_layout, o, chip); break;
+    case KK_L7_RGB:
+        // in_gdn: the input holds the previous layer's pre-activation lanes, its activation is applied on the way in (k_l7g.hip)
+        e = in_gdn ? launch_l7_gdn(g, *w, *in_gdn, in, out, n_images, stream, in_layout, o, chip)
+                   : launch_l7(g, *w, in, out, n_images, stream, in_layout, o, chip);
+        break;
     case KK_MFMA_CONV:
     case KK_MFMA_DECONV:
         // MFMA shape: 16x16x64 by default (higher sustained clock, k_mfma16.hip); mfma_shape = 32 selects
@@ -390,7 +396,8 @@ static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint
         break;
     default: e = launch_generic(g, *w, in, out, n_images, stream, relu); break;
     }
-    if (e == hipSuccess && gdn) e = launch_gdn(*gdn, out, out_layout, d->OFM_ROW, d->OFM_COL, n_images, stream);
+    if (in_gdn && layer_kernel(*d, o, gdn != nullptr) != KK_L7_RGB) return SICN_EINVAL;   // only that kernel takes one
+    if (e == hipSuccess && gdn && !defer_gdn) e = launch_gdn(*gdn, out, out_layout, d->OFM_ROW, d->OFM_COL, n_images, stream);
     if (e == hipErrorInvalidValue) return SICN_EINVAL;
     return e == hipSuccess ? SICN_OK : SICN_ENODEV;
 }
@@ -543,6 +550,17 @@ extern "C" size_t sicn_net_workspace_bytes(const sicn_net *net, int n_images)
     return 2 * pingpong_slot_bytes(net, n_images) + KSPLIT_MAX * ks.partial + align256(ks.words * sizeof(unsigned long long));
 }
 
+// Layer l's GDN / IGDN is applied by layer l + 1's kernel (k_l7g.hip) instead of k_gdn (sicn_options.gdn_fuse = 2): l + 1 is part of this call, takes the RGB
+// deconv kernel, has no activation of its own, and layer l's output is an intermediate nobody else reads.
+static bool gdn_moves_to_next(const sicn_net *net, int l, int last, int tap_layer)
+{
+    if (l >= last || l == tap_layer || !net->gdn[l] || net->gdn[l + 1]) return false;
+    if (net->opt.gdn_fuse != 2) return false;   // measured: no gain over k_gdn + k_l7 (k_l7g.hip), so only on request
+    const sicn_gdn *g = net->gdn[l];
+    return layer_kernel(net->descs[l + 1], net->opt, false) == KK_L7_RGB && g->channels == 128 && g->d_gamma_mfma != nullptr &&
+           net->weights[l + 1]->d_w_l7 != nullptr;
+}
+
 extern "C" int sicn_net_forward(const sicn_net *net, int first, int last, const uint8_t *in, uint8_t *out,
                                 int tap_layer, uint8_t *tap_out, int n_images, void *workspace,
                                 size_t workspace_bytes, void *hip_stream)
@@ -585,6 +603,7 @@ extern "C" int sicn_net_forward(const sicn_net *net, int first, int last, const 
         const int at = net->ev_next.fetch_add(need, std::memory_order_relaxed);
         if (at + need <= sicn_net::EV_RING) slot0 = at;   // ring full: this call is not timed
     }
+    const sicn_gdn *deferred = nullptr;    // the previous layer's activation, when it is this layer's to apply
     for (int l = first; l <= last; l++) {
         // a tapped layer (the latent) is written straight into the caller's buffer and the next layer reads it there: no copy
         // (round 3 copied it device-to-device behind the layer: 4.8 us per forward pass on small inputs, 15 us on 8 x 4K)
@@ -598,8 +617,12 @@ extern "C" int sicn_net_forward(const sicn_net *net, int first, int last, const 
             net->ev_layer[slot].store(-1, std::memory_order_relaxed);   // becomes l once both events are recorded
             if (hipEventRecord(net->ev_begin[slot], stream) != hipSuccess) return SICN_ENODEV;
         }
+        // the activation of layer l moves into layer l + 1's kernel where that kernel exists (128 channels -> RGB, k_l7g) and nobody
+        // else sees layer l's output: the activated tensor is then never written
+        const bool defer = gdn_moves_to_next(net, l, last, tap_layer);
         int rc = run_layer(&net->descs[l], net->weights[l], cur, dst, n_images, stream, -1, net->opt, cur_layout, out_layout,
-                           net->gdn[l], ks);
+                           net->gdn[l], ks, defer, deferred);
+        deferred = defer ? net->gdn[l] : nullptr;
         if (rc) return rc;
         if (slot >= 0) {
             if (hipEventRecord(net->ev_end[slot], stream) != hipSuccess) return SICN_ENODEV;

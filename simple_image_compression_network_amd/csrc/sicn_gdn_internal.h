@@ -17,6 +17,10 @@ hipError_t launch_gdn(const sicn_gdn &g, uint8_t *data, int layout, int W, int H
 // layer 0 (RGB -> 128 channels) and its GDN / IGDN in one kernel (k_l0g.hip): needs w.d_w_l0g and g.d_gamma_mfma
 hipError_t launch_l0_gdn(const LayerGeom &g, const sicn_weights &w, const sicn_gdn &gdn, const uint8_t *in, uint8_t *out, int n_images,
                          hipStream_t stream, int out_layout, const sicn_options &o, const ChipGeom &chip);
+// layer 7 (128 channels -> RGB) reading the pre-activation lanes of the layer before it and applying that layer's GDN / IGDN on the
+// way into its LDS window (k_l7g.hip): needs w.d_w_l7 and g.d_gamma_mfma
+hipError_t launch_l7_gdn(const LayerGeom &g, const sicn_weights &w, const sicn_gdn &gdn, const uint8_t *in, uint8_t *out, int n_images,
+                         hipStream_t stream, int in_layout, const sicn_options &o, const ChipGeom &chip);
 hipError_t launch_gdn_generic(const sicn_gdn &g, uint8_t *data, long long n_pos, hipStream_t stream);
 // the kernels' two integer roots against bisection for n_begin <= n < n_begin + count, on the device
 hipError_t gdn_selftest_roots(int inverse, uint32_t n_begin, unsigned long long count, unsigned long long *mismatches);

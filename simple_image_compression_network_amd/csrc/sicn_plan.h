@@ -89,6 +89,26 @@ inline int l7_chunks(int tiles_x, int n_images, int steps_y, int forced, const C
     return (int)y;
 }
 
+// ---- the RGB layer with the previous layer's activation (k_l7g): strips of 62 columns, steps of 4 rows, wgs_per_cu (1 or 2) workgroups per CU at a
+// time.  Every cut costs about two steps (the prologue activates six rows, two rounds of items): the cut with the fewest
+// step-times on the busiest CU, the smallest such
+inline int l7g_chunks(int tiles_x, int n_images, int steps_y, int forced, int wgs_per_cu, const ChipGeom &c)
+{
+    if (forced > 0) return forced < steps_y ? forced : steps_y;
+    const long strips = (long)tiles_x * n_images;
+    int best = 1;
+    long best_cost = -1;
+    for (int y = 1; y <= steps_y && y <= 64; y++) {
+        const long per = (steps_y + y - 1) / y, rounds = (strips * y + (long)wgs_per_cu * c.n_cu - 1) / ((long)wgs_per_cu * c.n_cu),
+                   cost = rounds * (per + 2);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = y;
+        }
+    }
+    return best;
+}
+
 // ---- layer 0 (k_l0): vertical runs of at most `max_run` tiles per workgroup, about four workgroups per CU on small images -----
 struct L0Cut { int y_chunks, ty_per; };
 inline L0Cut l0_chunks(int tiles_x, int tiles_y, int n_images, int max_run, int forced, const ChipGeom &c)

@@ -228,7 +228,7 @@ def test_gpu_wide_persistent_layer_with_gdn_equals_oracle(case, inverse, grid):
 
 
 @gpu
-@pytest.mark.parametrize("options", [{}, {"tile_x": 16}, {"no_phase_layout": 1}, {"force_generic": 1}, {"wave_tile": 128, "persistent_grid": 8}])
+@pytest.mark.parametrize("options", [{}, {"gdn_fuse": 2}, {"gdn_fuse": 1}, {"gdn_fuse": 2, "no_phase_layout": 1}, {"tile_x": 16}, {"no_phase_layout": 1}, {"force_generic": 1}, {"wave_tile": 128, "persistent_grid": 8}])
 def test_gpu_gdn_net_all_internal_layouts(options):
     """The hyperprior-style main transform: GDN after L0-L2, IGDN after L4-L6 (L3 and L7 keep the reference's ReLU), as one
     sicn_net chain.  The activations run in place on GROUP / PHASE / NHWC intermediates; latent and reconstruction must
@@ -314,3 +314,68 @@ def test_gpu_layer0_with_gdn_in_one_kernel_at_1080p():
     g = api.GDN(beta, gamma, False, 12)
     a = api.conv2d(d, fpw, b, xd, None, 2, gdn=g)
     assert torch.equal(a, api.conv2d(d, fpw, b, xd, None, 2, gdn=g, options={"gdn_fuse": 1}))
+
+
+def _rgb_tail_chain(rng, first_case, inverse, options={"gdn_fuse": 2}):
+    """(a 128-channel layer with a GDN / IGDN) -> (128 channels -> RGB deconv): the tail of the hyperprior's synthesis."""
+    from simple_image_compression_network_amd import api
+    d0 = _mk_desc(*first_case)
+    d1 = _mk_desc(128, 3, 8, 3, d0.OFM_ROW, d0.OFM_COL, 1)
+    layers = []
+    for d in (d0, d1):
+        Wt = rng.integers(-8, 8, (d.OFM_CH, 5, 5, d.IFM_CH)).astype(np.int8)
+        bt = rng.integers(-128, 128, d.OFM_CH).astype(np.int8)
+        layers.append((Wt, bt, d.transposed))
+    params = [(api.FixedPointWeights(d.SIMD, 4, d.PE, d.W_TILES, sicn_ref.pack_finn_tiles(Wt, d.SIMD, d.PE)),
+               api.FixedPointWeights(1, 8, 1, d.OFM_CH, bt.view(np.uint8).astype(np.uint64))) for d, (Wt, bt, _) in zip((d0, d1), layers)]
+    beta, gamma = _params(rng, 128)
+    net = api.EightLayersNet(descs=[d0, d1], params=params, gdn=[api.GDN(beta, gamma, inverse, 12), None], options=options)
+    return net, d0, layers, (beta, gamma)
+
+
+# first layer: (cin, cout, simd, pe, w, h, transposed) — its output is the RGB layer's input: 2 x 2 (one position per side), 16 x 10,
+# 34 x 18, 31 x 18 (odd width: byte stores), 62 x 40 (exactly one strip of 62 columns, ten steps of 4 rows), 90 x 66 (two strips:
+# 62 + 28), 126 x 14 (three strips: 62 + 62 + 2), 63 x 9 (conv: a strip of one column, odd height)
+RGB_TAIL = [(128, 128, 8, 16, 1, 1, 1), (128, 128, 8, 16, 8, 5, 1), (128, 128, 8, 16, 17, 9, 1), (128, 128, 8, 16, 61, 35, 0),
+            (128, 128, 8, 16, 31, 20, 1), (128, 128, 8, 16, 45, 33, 1), (128, 128, 8, 16, 63, 7, 1), (128, 128, 8, 16, 125, 17, 0)]
+
+
+@gpu
+@pytest.mark.parametrize("case", RGB_TAIL)
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gpu_rgb_layer_applies_previous_gdn_equals_oracle(case, inverse):
+    """k_l7g (round 4, sicn_options.gdn_fuse = 2): in a chain the 128 -> RGB layer reads the PRE-activation lanes of the layer before it
+    and applies that layer's GDN / IGDN on the way into its LDS window.  Against the oracle, against the three-kernel path (gdn_fuse = 0 / 1), with
+    the strips cut into 1 / 2 / 3 runs, and with the first layer tapped (its activated output is then wanted: no fusion)."""
+    import torch
+    rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + 3 * inverse)
+    net, d0, layers, (beta, gamma) = _rgb_tail_chain(rng, case, inverse)
+    x = rng.integers(0, 128, (2,) + d0.in_shape, dtype=np.uint8)
+    xd = torch.from_numpy(x).cuda()
+    got = net.run_layers(0, 1, xd)[0].cpu().numpy()
+    for i in range(2):
+        pre = sicn_ref.layer_preact_ref(x[i], layers[0][0], layers[0][1], layers[0][2])
+        mid = c_oracle.gdn(pre, beta, gamma, inverse, 12)
+        assert np.array_equal(got[i], sicn_ref.deconv522_ref(mid, layers[1][0], layers[1][1])), i
+    for opt in ({"gdn_fuse": 1}, {"gdn_fuse": 0}, {"strip_chunks": 1}, {"strip_chunks": 2}, {"strip_chunks": 3}, {"strip_chunks": 7}, {"no_phase_layout": 1}, {"tile_x": 16}):
+        opt = dict({"gdn_fuse": 2}, **opt)
+        rng2 = np.random.default_rng(abs(hash(case)) % (1 << 31) + 3 * inverse)
+        net2 = _rgb_tail_chain(rng2, case, inverse, opt)[0]
+        assert np.array_equal(got, net2.run_layers(0, 1, xd)[0].cpu().numpy()), opt
+    out, tap = net.run_layers(0, 1, xd, tap_layer=0)
+    assert np.array_equal(out.cpu().numpy(), got)
+    pre = sicn_ref.layer_preact_ref(x[1], layers[0][0], layers[0][1], layers[0][2])
+    assert np.array_equal(tap[1].cpu().numpy(), c_oracle.gdn(pre, beta, gamma, inverse, 12))
+
+
+@gpu
+def test_gpu_rgb_layer_applies_previous_gdn_at_1080p_input():
+    """One workgroup of 1024 threads on every CU, 16 strips x 135 steps cut by sicn_plan.h: 960 x 540 -> (IGDN) -> 1920 x 1080 x 128 -> RGB 3840 x 2160,
+    against the three-kernel path."""
+    import torch
+    rng = np.random.default_rng(9)
+    net, d0, _, _ = _rgb_tail_chain(rng, (128, 128, 8, 16, 960, 540, 1), True)
+    rng = np.random.default_rng(9)
+    ref = _rgb_tail_chain(rng, (128, 128, 8, 16, 960, 540, 1), True, {"gdn_fuse": 1})[0]
+    xd = torch.from_numpy(np.random.default_rng(1).integers(0, 128, (1,) + d0.in_shape, dtype=np.uint8)).cuda()
+    assert torch.equal(net.run_layers(0, 1, xd)[0], ref.run_layers(0, 1, xd)[0])
