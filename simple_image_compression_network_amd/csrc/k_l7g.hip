@@ -22,31 +22,38 @@
 // MEASURED (r04, rocprof, 8 x 4K hyperprior step): 2.17 ms against 1.62 ms (k_gdn on the 2.1 GB tensor) + 0.49 ms (k_l7) = 2.11 ms for
 // the two kernels it replaces — NO gain, so sicn_options.gdn_fuse has to ask for it (= 2); DESIGN.md section 11.  The activation
 // is bound by VALU issue and k_l7 by its fragment reads from LDS and their address arithmetic, not by the HBM traffic the fusion
-// removes, and in one kernel the two simply add (the consumer also reads W' from LDS here: 36 instead of 18 KB per tile).  On the
-// way: a first geometry (30 + 2 columns, 16 rows per step, consumer and loader phases separated by a second barrier, 18-row ring)
-// came to ~2.0 ms; two s_waitcnt vmcnt(0) that hipcc placed right behind the step's store (see request() and the loop) cost 0.1 ms.
+// removes, and in one kernel the two simply add (the consumer also reads W' from LDS here: 36 instead of 18 KB per tile).  Neither
+// two workgroups per CU instead of one (so it is not the wait at the step barrier) nor separate consumer and loader phases (so
+// it is not the two interfering in LDS) changes that: 2.17 / 2.17 / 2.23 ms, see L7G below.  Two s_waitcnt vmcnt(0) that hipcc
+// had placed right behind the step's store (see request() and the loop) were worth 0.1 ms.
 // Out-of-image positions load 0 and activate to 0 (x = 0 -> y = 0 for GDN and IGDN alike): the deconv's zero padding.
 #include "k_gdn_body.hpp"
 #include "sicn_gdn_internal.h"
 
 namespace sicn {
 
-// Geometry G: PITCH window positions per row (PITCH - 2 columns of outputs), WAVES waves per workgroup; a step is ROWS = 4 rows =
-// WAVES items of 16 positions and WAVES tiles of 16 positions: one of each per wave.  Built: (64, 16) — 62-column strips, 1024
-// threads, one workgroup per CU, ring 80 KB.  (32, 8) — 30-column strips, 512 threads, two workgroups per CU — measured the same
-// (2.17 ms on the 8 x 4K tensor either way), so the one with the smaller halo stays.
-template <int PITCH_, int WAVES_>
+// Geometry G: PITCH window positions per row (PITCH - 2 columns of outputs), WAVES waves per workgroup, ROWS input rows per step =
+// ROWS * PITCH / 16 items of 16 positions and as many consumer tiles, IPW of each per wave.
+//   SERIAL = false: the loader writes the rows of step t + 1 while step t is consumed (k_l7's rolling ring, 2 ROWS + 2 rows, one
+//                   barrier per step);
+//   SERIAL = true:  consumer phase, barrier, loader phase over the rows just freed, barrier: ROWS + 2 rows are enough, so a step can
+//                   be four times as many rows in the same LDS.
+// Built and measured on the 8 x 4K tensor: <64, 16, 4, false> (62-column strips, one 1024-thread workgroup per CU) and
+// <32, 8, 4, false> (30 columns, two 512-thread workgroups per CU) 2.17 ms both; <32, 16, 16, true> (two items and two tiles per
+// wave and phase) 2.23 ms.  Only the first is instantiated.
+template <int PITCH_, int WAVES_, int ROWS_, bool SERIAL_>
 struct L7G {
-    static constexpr int PITCH = PITCH_, WAVES = WAVES_, COLS = PITCH - 2, TPR = PITCH / 16, ROWS = WAVES / TPR;
-    static constexpr int BLOCK_PIECES = ROWS * PITCH / 16;            // items per step
-    static constexpr int PROLOGUE_PIECES = (ROWS + 2) * PITCH / 16;   // the 6 rows the first step reads
-    static constexpr int RING_PIECES = (2 * ROWS + 2) * PITCH / 16;   // the rows one step reads + the rows the next one adds
+    static constexpr int PITCH = PITCH_, WAVES = WAVES_, ROWS = ROWS_, COLS = PITCH - 2, TPR = PITCH / 16;
+    static constexpr bool SERIAL = SERIAL_;
+    static constexpr int BLOCK_PIECES = ROWS * TPR;                   // items per step = tiles per step
+    static constexpr int IPW = BLOCK_PIECES / WAVES;                  // of each per wave
+    static constexpr int PROLOGUE_PIECES = (ROWS + 2) * TPR;          // the rows the first step reads
+    static constexpr int RING_PIECES = ((SERIAL ? ROWS : 2 * ROWS) + 2) * TPR;
     static constexpr int RING_POS = RING_PIECES * 16, REGION = RING_PIECES * 1024;
-    static constexpr int WBYTES = 18 * 16 * 64, GAMMA = 128 * 128, STAGE = 192;   // stage: 2 output rows x 32 pixels x 3 B per wave
-    static constexpr int LDS = 2 * REGION + WBYTES + GAMMA + 512 + WAVES * STAGE;
+    static constexpr int WBYTES = 18 * 16 * 64, GAMMA = 128 * 128, STAGE = 192;   // stage: 2 output rows x 32 pixels x 3 B per tile
+    static constexpr int LDS = 2 * REGION + WBYTES + GAMMA + 512 + WAVES * IPW * STAGE;
     static constexpr int WGS_PER_CU = (160 * 1024) / LDS >= 2 ? 2 : 1;
-    static_assert(ROWS == 4 && BLOCK_PIECES == WAVES, "one item and one tile per wave and step");
-    static_assert(PROLOGUE_PIECES <= 2 * WAVES, "the prologue is two rounds of items");
+    static_assert(IPW * WAVES == BLOCK_PIECES && IPW >= 1 && (TPR % IPW == 0 || IPW % TPR == 0), "whole items and tiles per wave");
     static_assert(LDS * WGS_PER_CU <= 160 * 1024 && WAVES * WGS_PER_CU <= 16, "LDS and <= 128 VGPRs");
 };
 
@@ -59,7 +66,7 @@ __global__ __launch_bounds__(G::WAVES * 64, G::WGS_PER_CU) void k_l7g(const uint
 {
     constexpr int L7G_COLS = G::COLS, L7G_PITCH = G::PITCH, L7G_ROWS = G::ROWS, L7G_WAVES = G::WAVES, L7G_BLOCK_PIECES = G::BLOCK_PIECES,
                   L7G_PROLOGUE_PIECES = G::PROLOGUE_PIECES, L7G_RING_PIECES = G::RING_PIECES, L7G_RING_POS = G::RING_POS,
-                  L7G_REGION = G::REGION, L7G_WBYTES = G::WBYTES, L7G_GAMMA = G::GAMMA, L7G_STAGE = G::STAGE, TPR = G::TPR;
+                  L7G_REGION = G::REGION, L7G_WBYTES = G::WBYTES, L7G_GAMMA = G::GAMMA, L7G_STAGE = G::STAGE, TPR = G::TPR, IPW = G::IPW;
     constexpr int CIN = 128;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *patch = smem;
@@ -92,9 +99,9 @@ __global__ __launch_bounds__(G::WAVES * 64, G::WGS_PER_CU) void k_l7g(const uint
     uint8_t *out_img = out + (size_t)img * OH * OW * 3;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)in_img, 0, in_img_bytes, 0x00020000);
     const TensorMap tm = tensor_map(in_layout, CIN, IW, IH);
-    // window row r <-> input row iy_top + r; window position q = 64 r + tx <-> column X0 - 1 + tx; ring slot q mod 640.
-    // Piece p = positions 16 p .. + 15: the prologue computes pieces 0 .. 23 (rows 0 .. 5), step t adds block t = pieces 24 + 16 t .. + 15
-    // (rows 6 + 4 t .. 9 + 4 t: what step t + 1 reads beyond the two rows it shares with step t).
+    // window row r <-> input row iy_top + r; window position q = PITCH r + tx <-> column X0 - 1 + tx; ring slot q mod RING_POS.
+    // Piece p = positions 16 p .. + 15: the prologue computes the rows 0 .. ROWS + 1 the first step reads, step t adds block t = the
+    // ROWS rows step t + 1 reads beyond the two it shares with step t (<64, 16, 4>: pieces 24 + 16 t .. + 15 = rows 6 + 4 t .. 9 + 4 t).
     const int iy_top = L7G_ROWS * s_begin - 1;
     const int iy_max = min(IH, L7G_ROWS * s_end + 1);   // one past the last row this chunk reads
     auto request = [&](int piece, v4i (&x)[2]) {
@@ -119,79 +126,96 @@ __global__ __launch_bounds__(G::WAVES * 64, G::WGS_PER_CU) void k_l7g(const uint
             *(v4i *)(patch + J * L7G_REGION + P * 64u + ((((uint32_t)kg) ^ ((P >> 2) & 3u)) << 4)) = y[J];
     };
     const int n_steps = s_end - s_begin;
-    v4i xa[2], xn[2];
-    request(w, xa);
-    if (w + L7G_WAVES < L7G_PROLOGUE_PIECES) request(w + L7G_WAVES, xn);
+    v4i xn[2];
     block_barrier();                       // gamma and beta are there
-    activate(w, xa);
-    if (w + L7G_WAVES < L7G_PROLOGUE_PIECES) activate(w + L7G_WAVES, xn);
-    request(L7G_PROLOGUE_PIECES + w, xn);   // block 0, worked on in step 0
+    for (int piece = w; piece < L7G_PROLOGUE_PIECES; piece += L7G_WAVES) {   // once per chunk: not pipelined
+        request(piece, xn);
+        activate(piece, xn);
+    }
+    request(L7G_PROLOGUE_PIECES + w, xn);   // block 0's first item, worked on in step 0
     block_barrier();
     asm volatile("" : "+v"(xn[0]), "+v"(xn[1]));   // (as in the loop: no load of the prologue is pending in hipcc's books past this point)
 
     const int py = kg >> 1, px = kg & 1;
-    const int wr = w / TPR, tc = w % TPR;     // the wave's tile of a step: row wr, columns 16 tc .. + 15 of the strip
-    uint8_t *my_stage = stage + w * L7G_STAGE;
     const int cols_here = min(L7G_COLS, IW - X0);
-    const int valid = max(0, min(16, cols_here - 16 * tc));            // columns of this tile inside the strip
     const bool fast_rows = ((OW * 3) & 3) == 0 && (cols_here & 1) == 0;   // whole dwords per output row of every tile
-    const int row_dw = 3 * valid / 2;                                   // 6 valid bytes / 4
     __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)out_img, 0, OH * OW * 3, 0x00020000);
-    int base = 0;                          // (256 t) mod 640: ring slot of window row 4 t, column 0
-    for (int t = 0; t < n_steps; t++) {
-        // ---- loader: this wave's item of block t (the rows step t + 1 adds), requested one step ago ------------------------------
-        // Unconditional, also in the last steps of a chunk (rows past iy_max load nothing and activate to 0 in slots nobody reads
-        // any more): with the two conditions around it hipcc lost count of what is in flight and opened every step with
-        // s_waitcnt vmcnt(0) — a wait for the store issued a moment earlier, a fifth of the step.
-        {
+    int base = 0;                          // (ROWS PITCH t) mod ring: ring slot of window row ROWS t, column 0
+    // ---- loader: this wave's items of block t (the rows step t + 1 adds); the first one's bytes were requested a step ago -----------
+    // Unconditional, also in the last step of a chunk (rows past iy_max load nothing and activate to 0 in slots nobody reads any
+    // more): with conditions around it hipcc lost count of what is in flight and opened every step with s_waitcnt vmcnt(0) — a
+    // wait for the store issued a moment earlier, a fifth of the step.
+    auto loader = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < IPW; i++) {
             const v4i xf[2] = {xn[0], xn[1]};
-            request(L7G_PROLOGUE_PIECES + L7G_BLOCK_PIECES * (t + 1) + w, xn);
-            activate(L7G_PROLOGUE_PIECES + L7G_BLOCK_PIECES * t + w, xf);
-            // the next item's bytes are taken out of hipcc's load bookkeeping HERE, an item's time after their request and before
-            // this step's store is issued: left to itself it rotates the registers at the bottom of the loop, behind the store, with
-            // an s_waitcnt vmcnt(0)
+            const int piece = L7G_PROLOGUE_PIECES + L7G_BLOCK_PIECES * t + w + L7G_WAVES * i;
+            request(i + 1 < IPW ? piece + L7G_WAVES : L7G_PROLOGUE_PIECES + L7G_BLOCK_PIECES * (t + 1) + w, xn);
+            activate(piece, xf);
+            // the next item's bytes are taken out of hipcc's load bookkeeping HERE, an item's time after their request and not behind
+            // a store: left to itself it rotates the registers at the bottom of the loop, behind the step's store, with a vmcnt(0)
             asm volatile("" : "+v"(xn[0]), "+v"(xn[1]));
         }
-        // ---- consumer: input row 4 s + wr, 16 positions -------------------------------------------------------------------------
-        v4i acc = v4i{b0, b1, b2, 0};      // C row 4 kg + r = phase kg, channel r
+    };
+    for (int t = 0; t < n_steps; t++) {
+        if constexpr (!G::SERIAL) loader(t);
+        // ---- consumer: tiles IPW w .. IPW w + IPW - 1 of the step (tile tau: row tau / TPR, columns 16 (tau % TPR) .. + 15) -----------
+        v4i acc[IPW];
+#pragma unroll
+        for (int i = 0; i < IPW; i++) acc[i] = v4i{b0, b1, b2, 0};      // C row 4 kg + r = phase kg, channel r
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             const v4i wf0 = *(const v4i *)(wl + ((tap * 2 + 0) * 16 + m) * 64 + kg * 16);
             const v4i wf1 = *(const v4i *)(wl + ((tap * 2 + 1) * 16 + m) * 64 + kg * 16);
-            uint32_t slot = (uint32_t)(base + (wr + tap / 3) * L7G_PITCH + 16 * tc + m + tap % 3);
-            slot = min(slot, slot - (uint32_t)L7G_RING_POS);   // one wrap at most
-            const uint32_t addr = (uint32_t)((kg & 1) * L7G_REGION) + slot * 64u + ((((uint32_t)(kg >> 1)) ^ ((slot >> 2) & 3u)) << 4);
-            const v4i p0 = *(const v4i *)(patch + addr);
-            const v4i p1 = *(const v4i *)(patch + (addr ^ 32u));   // channels + 32: chunk ^ 2
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf0, p0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf1, p1, acc, 0, 0, 0);
-        }
-        const int gy = L7G_ROWS * (s_begin + t) + wr;
-        const uint32_t v = pack4_relu7(acc[0], acc[1], acc[2], 0);
-        if (fast_rows) {
-            // stage [2 rows = py][32 pixels = 2 m + px][3] and write the rows as dwords
-            if (m < valid) {
-                uint8_t *d = my_stage + py * 96 + (2 * m + px) * 3;
-                d[0] = (uint8_t)v;
-                d[1] = (uint8_t)(v >> 8);
-                d[2] = (uint8_t)(v >> 16);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private staging: no barrier needed
-            const int row = lane >= row_dw ? 1 : 0, col = lane - row_dw * row;
-            const bool ok = lane < 2 * row_dw && gy < IH;
-            const uint32_t sv = *(const uint32_t *)(my_stage + (ok ? row * 96 + col * 4 : 0));
-            const uint32_t off = ok ? (uint32_t)(((2 * gy + row) * OW + 2 * (X0 + 16 * tc)) * 3 + col * 4) : OOB;
-            __builtin_amdgcn_raw_buffer_store_b32(sv, ro, off, 0, 0);
-        } else {
-            const int gx = X0 + 16 * tc + m;
-            if (gy < IH && m < valid) {
-                uint8_t *dst = out_img + ((size_t)(2 * gy + py) * OW + 2 * gx + px) * 3;
-                dst[0] = (uint8_t)v;
-                dst[1] = (uint8_t)(v >> 8);
-                dst[2] = (uint8_t)(v >> 16);
+#pragma unroll
+            for (int i = 0; i < IPW; i++) {
+                const int tau = w * IPW + i, wr = tau / TPR, tc = tau % TPR;
+                uint32_t slot = (uint32_t)(base + (wr + tap / 3) * L7G_PITCH + 16 * tc + m + tap % 3);
+                slot = min(slot, slot - (uint32_t)L7G_RING_POS);   // one wrap at most
+                const uint32_t addr = (uint32_t)((kg & 1) * L7G_REGION) + slot * 64u + ((((uint32_t)(kg >> 1)) ^ ((slot >> 2) & 3u)) << 4);
+                const v4i p0 = *(const v4i *)(patch + addr);
+                const v4i p1 = *(const v4i *)(patch + (addr ^ 32u));   // channels + 32: chunk ^ 2
+                acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf0, p0, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf1, p1, acc[i], 0, 0, 0);
             }
         }
-        block_barrier();   // block t is complete for every wave, the rows of step t are free
+#pragma unroll
+        for (int i = 0; i < IPW; i++) {
+            const int tau = w * IPW + i, wr = tau / TPR, tc = tau % TPR;
+            const int gy = L7G_ROWS * (s_begin + t) + wr;
+            const int valid = max(0, min(16, cols_here - 16 * tc));            // columns of this tile inside the strip
+            const int row_dw = 3 * valid / 2;                                   // 6 valid bytes / 4
+            uint8_t *my_stage = stage + (w * IPW + i) * L7G_STAGE;
+            const uint32_t v = pack4_relu7(acc[i][0], acc[i][1], acc[i][2], 0);
+            if (fast_rows) {
+                // stage [2 rows = py][32 pixels = 2 m + px][3] and write the rows as dwords
+                if (m < valid) {
+                    uint8_t *d = my_stage + py * 96 + (2 * m + px) * 3;
+                    d[0] = (uint8_t)v;
+                    d[1] = (uint8_t)(v >> 8);
+                    d[2] = (uint8_t)(v >> 16);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private staging: no barrier needed
+                const int row = lane >= row_dw ? 1 : 0, col = lane - row_dw * row;
+                const bool ok = lane < 2 * row_dw && gy < IH;
+                const uint32_t sv = *(const uint32_t *)(my_stage + (ok ? row * 96 + col * 4 : 0));
+                const uint32_t off = ok ? (uint32_t)(((2 * gy + row) * OW + 2 * (X0 + 16 * tc)) * 3 + col * 4) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b32(sv, ro, off, 0, 0);
+            } else {
+                const int gx = X0 + 16 * tc + m;
+                if (gy < IH && m < valid) {
+                    uint8_t *dst = out_img + ((size_t)(2 * gy + py) * OW + 2 * gx + px) * 3;
+                    dst[0] = (uint8_t)v;
+                    dst[1] = (uint8_t)(v >> 8);
+                    dst[2] = (uint8_t)(v >> 16);
+                }
+            }
+        }
+        block_barrier();   // !SERIAL: block t is complete for every wave, the rows of step t are free; SERIAL: the latter
+        if constexpr (G::SERIAL) {
+            loader(t);     // over the ROWS rows just freed
+            block_barrier();
+        }
         base += L7G_ROWS * L7G_PITCH;
         base = base >= L7G_RING_POS ? base - L7G_RING_POS : base;
     }
@@ -215,7 +239,7 @@ hipError_t launch_l7_gdn(const LayerGeom &g, const sicn_weights &w, const sicn_g
                            gdn.d_beta, g.IW, g.IH, g.OW, g.OH, steps_y, y_chunks, tiles_x, in_layout, gdn.shift);
         return hipGetLastError();
     };
-    using Wide = L7G<64, 16>;
+    using Wide = L7G<64, 16, 4, false>;
     return gdn.inverse ? go(k_l7g<true, Wide>, Wide{}) : go(k_l7g<false, Wide>, Wide{});
 }
 
