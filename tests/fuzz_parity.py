@@ -20,6 +20,8 @@ ap.add_argument("--cases", type=int, default=200)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--big", action="store_true", help="image sizes up to 600 x 400 (slow on the CPU side)")
 ap.add_argument("--chains", type=int, default=0, help="additionally: whole 8-layer chains (internal layouts) on random sizes")
+ap.add_argument("--gdn", type=int, default=0, help="additionally: layer 0 + GDN in one kernel (k_l0g) and (layer + GDN) -> RGB layer chains with the "
+                "activation applied by the RGB layer (k_l7g), random sizes, against the C oracle of the GDN")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 
@@ -45,7 +47,11 @@ for case in range(args.cases):
         env["tile_x"] = int(rng.choice([16, 32]))
     if rng.random() < 0.3:
         env["split_n"] = int(rng.choice([1, 2, 4]))
-    if rng.random() < 0.4:       # the wide persistent kernels (only conv / deconv 128 -> 128 take them; others ignore the request)
+    if cin == 3 and rng.random() < 0.3:      # the persistent layer-0 kernel (k_l0p), 1 .. all workgroups
+        env["l0_form"] = 2
+        env.pop("strip_chunks", None)
+        env["persistent_grid"] = int(rng.choice([1, 3, 8, 64, 0]))
+    if cin != 3 and rng.random() < 0.4:       # the wide persistent kernels (only conv / deconv 128 -> 128 take them; others ignore the request)
         env["wave_tile"] = 128
         env["tile_x"] = 32
         env["persistent_grid"] = int(rng.choice([8, 16, 64, 0]))
@@ -109,4 +115,55 @@ for case in range(args.chains):
         print(f"chain {case}: ok ({w}x{h} n={n})", flush=True)
 if args.chains:
     print(f"{args.chains - cbad}/{args.chains} chains bit-exact")
-sys.exit(1 if (bad or cbad) else 0)
+
+# the activation inside the layer kernels (extension beyond the reference): against oracle/sicn_gdn_oracle.c
+gbad = 0
+if args.gdn:
+    from oracle import c_oracle  # noqa: E402  (checker)
+for case in range(args.gdn):
+    inverse = bool(rng.integers(2))
+    beta = rng.integers(1, 65536, 128).astype(np.uint32)
+    gamma = rng.integers(0, 128, (128, 128)).astype(np.uint8)
+    if rng.random() < 0.5:
+        gamma = (gamma >> 4).astype(np.uint8)
+    env = {}
+    if rng.random() < 0.5:
+        env["strip_chunks"] = int(rng.integers(1, 7))
+    n = int(rng.integers(1, 4))
+    def mk(cin, cout, simd, pe, w, h, tr):
+        ow, oh = (2 * w, 2 * h) if tr else ((w + 1) // 2, (h + 1) // 2)
+        d = LayerDesc(IFM_CH=cin, IFM_ROW=w, IFM_COL=h, OFM_CH=cout, OFM_ROW=ow, OFM_COL=oh, SIMD=simd, PE=pe,
+                      W_TILES=(cout // pe) * (25 * cin // simd), transposed=tr)
+        d.validate()
+        Wt = rng.integers(-8, 8, (cout, 5, 5, cin)).astype(np.int8)
+        bt = rng.integers(-128, 128, cout).astype(np.int8)
+        return d, Wt, bt
+    if case % 2 == 0:     # k_l0g
+        d, Wt, bt = mk(3, 128, 3, 8, int(rng.integers(1, 300)), int(rng.integers(1, 200)), 0)
+        x = rng.integers(0, 256, (n,) + d.in_shape, dtype=np.uint8)
+        g = api.GDN(beta, gamma, inverse, 12)
+        fpw = api.FixedPointWeights(d.SIMD, 4, d.PE, d.W_TILES, sicn_ref.pack_finn_tiles(Wt, d.SIMD, d.PE))
+        got = api.conv2d(d, fpw, bt, torch.from_numpy(x).cuda(), None, n, gdn=g, options=env or None).cpu().numpy()
+        ok = all(np.array_equal(got[i], c_oracle.gdn(sicn_ref.layer_preact_ref(x[i], Wt, bt, 0), beta, gamma, inverse, 12)) for i in range(n))
+        what = f"k_l0g {d.IFM_ROW}x{d.IFM_COL}"
+    else:                 # (conv or deconv 128 -> 128, GDN) -> 128 -> RGB with gdn_fuse = 2
+        tr = int(rng.integers(2))
+        d0, W0, b0 = mk(128, 128, 8, 16, int(rng.integers(1, 70)), int(rng.integers(1, 40)), tr)
+        d1, W1, b1 = mk(128, 3, 8, 3, d0.OFM_ROW, d0.OFM_COL, 1)
+        params = [(api.FixedPointWeights(d.SIMD, 4, d.PE, d.W_TILES, sicn_ref.pack_finn_tiles(Wt, d.SIMD, d.PE)),
+                   api.FixedPointWeights(1, 8, 1, d.OFM_CH, bt.view(np.uint8).astype(np.uint64))) for d, Wt, bt in ((d0, W0, b0), (d1, W1, b1))]
+        env["gdn_fuse"] = 2
+        net = api.EightLayersNet(descs=[d0, d1], params=params, gdn=[api.GDN(beta, gamma, inverse, 12), None], options=env)
+        x = rng.integers(0, 128, (n,) + d0.in_shape, dtype=np.uint8)
+        got = net.run_layers(0, 1, torch.from_numpy(x).cuda())[0].cpu().numpy()
+        ok = all(np.array_equal(got[i], sicn_ref.deconv522_ref(c_oracle.gdn(sicn_ref.layer_preact_ref(x[i], W0, b0, tr), beta, gamma, inverse, 12), W1, b1))
+                 for i in range(n))
+        what = f"k_l7g behind {'deconv' if tr else 'conv'} {d0.IFM_ROW}x{d0.IFM_COL}"
+    if not ok:
+        gbad += 1
+        print(f"GDN MISMATCH {case}: {what} n={n} inverse={inverse} env={env}", flush=True)
+    elif case % 10 == 0:
+        print(f"gdn {case}: ok ({what} n={n} inverse={inverse} {env})", flush=True)
+if args.gdn:
+    print(f"{args.gdn - gbad}/{args.gdn} fused-activation cases bit-exact")
+sys.exit(1 if (bad or cbad or gbad) else 0)
