@@ -39,14 +39,19 @@ void sicn_gdn_free(sicn_gdn *g);
 /* The activation alone, IN PLACE over [n_positions][channels] lanes (an NHWC tensor of any image shape). */
 int sicn_gdn_apply(const sicn_gdn *g, uint8_t *lanes_nhwc, long long n_positions, void *hip_stream);
 
-/* conv2d<> / deconv522<> with the activation in place of the ReLU (gdn == NULL: the reference layer). */
+/* conv2d<> / deconv522<> with the activation in place of the ReLU (gdn == NULL: the reference layer).  Which kernels run is not
+ * part of the contract — the bytes are: by default the layer kernel stores its pre-activation lanes and the activation kernel
+ * rewrites them in place, except for conv2d 3 -> 128 channels, which applies the activation itself before its one store
+ * (sicn_options.gdn_fuse, sicn.h). */
 int sicn_conv2d_gdn(const sicn_layer_desc *desc, const sicn_weights *w, const sicn_gdn *gdn, const uint8_t *in_nhwc,
                     uint8_t *out_nhwc, int n_images, const sicn_options *opt, void *hip_stream);
 int sicn_deconv522_gdn(const sicn_layer_desc *desc, const sicn_weights *w, const sicn_gdn *gdn, const uint8_t *in_nhwc,
                        uint8_t *out_nhwc, int n_images, const sicn_options *opt, void *hip_stream);
 
 /* A chain whose layer i uses gdn[i] (NULL entries: the reference ReLU); gdn[i]'s channel count must equal
- * descs[i].OFM_CH.  The net keeps references to the activations (caller keeps them alive). */
+ * descs[i].OFM_CH.  The net keeps references to the activations (caller keeps them alive).  With sicn_options.gdn_fuse = 2 an
+ * intermediate layer's activation may be applied by the NEXT layer's kernel on the way in (128 channels -> RGB); a tapped layer's
+ * output and the chain's last output are always the activated bytes. */
 int sicn_net_create_gdn(const sicn_layer_desc *descs, sicn_weights *const *weights, const sicn_gdn *const *gdn,
                         int n_layers, const sicn_options *opt, sicn_net **out);
 
