@@ -240,6 +240,7 @@ hipError_t launch_l7_gdn(const LayerGeom &g, const sicn_weights &w, const sicn_g
         return hipGetLastError();
     };
     using Wide = L7G<64, 16, 4, false>;
+    static_assert(Wide::COLS == L7G_PLAN_COLS && Wide::ROWS == L7G_PLAN_ROWS && Wide::WGS_PER_CU == 1, "sicn_debug_plan mirrors this geometry");
     return gdn.inverse ? go(k_l7g<true, Wide>, Wide{}) : go(k_l7g<false, Wide>, Wide{});
 }
 

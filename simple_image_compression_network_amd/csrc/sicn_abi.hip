@@ -736,6 +736,10 @@ extern "C" int sicn_debug_plan(const sicn_layer_desc *d, int n_images, const sic
         const MfmaPlan p = plan_mfma(g, n_images, o, chip);
         out[3] = p.family; out[4] = p.tile_x; out[5] = p.split_n; out[6] = p.split_k;
         out[7] = (int)p.grid_x; out[8] = (int)p.grid_y; out[9] = (int)p.grid_z;
+    } else if (k == KK_L7_RGB && o.gdn_fuse == 2) {   // as the layer runs behind a layer with an activation in a chain (k_l7g)
+        const int tiles_x = (g.IW + L7G_PLAN_COLS - 1) / L7G_PLAN_COLS, steps_y = (g.IH + L7G_PLAN_ROWS - 1) / L7G_PLAN_ROWS;
+        const int yc = l7g_chunks(tiles_x, n_images, steps_y, o.strip_chunks, 1, chip);
+        out[7] = tiles_x * yc * n_images; out[8] = 1; out[9] = 1; out[10] = yc; out[11] = (steps_y + yc - 1) / yc;
     } else if (k == KK_L7_RGB) {
         const int tiles_x = (g.IW + 31) / 32, steps_y = (g.IH + 3) / 4;
         const int yc = l7_chunks(tiles_x, n_images, steps_y, o.strip_chunks, chip);

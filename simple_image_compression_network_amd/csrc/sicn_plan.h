@@ -92,6 +92,7 @@ inline int l7_chunks(int tiles_x, int n_images, int steps_y, int forced, const C
 // ---- the RGB layer with the previous layer's activation (k_l7g): strips of 62 columns, steps of 4 rows, wgs_per_cu (1 or 2) workgroups per CU at a
 // time.  Every cut costs about two steps (the prologue activates six rows, two rounds of items): the cut with the fewest
 // step-times on the busiest CU, the smallest such
+constexpr int L7G_PLAN_COLS = 62, L7G_PLAN_ROWS = 4;   // the geometry k_l7g.hip instantiates (static_assert there)
 inline int l7g_chunks(int tiles_x, int n_images, int steps_y, int forced, int wgs_per_cu, const ChipGeom &c)
 {
     if (forced > 0) return forced < steps_y ? forced : steps_y;

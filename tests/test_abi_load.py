@@ -161,3 +161,15 @@ def test_launch_planning_follows_the_chip_size_without_gpu():
     assert p0["ty_per"] <= 9 and p0["gy"] * p0["ty_per"] >= (1080 + 7) // 8
     d768 = eight_layer_descs(768, 512)
     assert _plan(d768[0], 1, 256)["gy"] == 32 and _plan(d768[0], 1, 32)["gy"] == 11
+    # the RGB layer behind a layer with an activation (k_l7g, gdn_fuse = 2): strips of 62 columns, steps of 4 rows, one workgroup per
+    # CU at a time; the cut = fewest step-times on the busiest CU (a cut costs about two steps), the smallest such
+    def l7g_cut(iw, ih, n, n_cu):
+        strips, steps = (iw + 61) // 62 * n, (ih + 3) // 4
+        cost = lambda y: -(-strips * y // n_cu) * (-(-steps // y) + 2)
+        return min(range(1, min(steps, 64) + 1), key=lambda y: (cost(y), y))
+    for d, n in ((d4k[7], 8), (d1080[7], 1), (d768[7], 2)):
+        for n_cu in (256, 128, 32):
+            p = _plan(d, n, n_cu, gdn_fuse=2)
+            yc = l7g_cut(d.IFM_ROW, d.IFM_COL, n, n_cu)
+            assert p["chunks"] == yc and p["gx"] == (d.IFM_ROW + 61) // 62 * yc * n and p["ty_per"] * yc >= (d.IFM_COL + 3) // 4, (n, n_cu, p)
+    assert _plan(d4k[7], 8, 256, gdn_fuse=2)["chunks"] == 1 and _plan(d1080[7], 1, 256, gdn_fuse=2)["chunks"] == 16   # 960 x 544: 16 strips x 16 runs of 9 steps = one workgroup per CU
