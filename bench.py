@@ -47,7 +47,8 @@ sys.path.insert(0, str(ROOT))
 PEAK_INT8_TOPS = 5000.0   # dense int8 MFMA = 2x the ~2.5 PFLOP/s bf16 dense peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0     # HBM3E spec
 NOMINAL_SCLK_MHZ = 2400.0  # the shader clock the nominal MFMA peak is quoted at
-KERNEL_SOURCES = ("k_common.hpp", "k_mfma16.hip", "k_mfma16p.hip", "k_mfma16x.hip", "k_mfma.hip", "k_rgb.hip", "k_generic.hip", "sicn_abi.hip")
+KERNEL_SOURCES = ("k_common.hpp", "k_l0_common.hpp", "k_mfma16.hip", "k_mfma16p.hip", "k_mfma16x.hip", "k_mfma.hip", "k_rgb.hip", "k_generic.hip", "sicn_plan.h",
+                  "sicn_abi.hip")   # what the eight layers of the headline run through (kernels + every launch decision)
 
 
 def kernel_source_fingerprint() -> str:
