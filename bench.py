@@ -51,12 +51,24 @@ KERNEL_SOURCES = ("k_common.hpp", "k_l0_common.hpp", "k_mfma16.hip", "k_mfma16p.
                   "sicn_abi.hip")   # what the eight layers of the headline run through (kernels + every launch decision)
 
 
-def kernel_source_fingerprint() -> str:
+# what the secondary legs (with_coder, hyperprior) run through on top of that: the coders and the activation (the
+# profiles/rNN_hyperprior_* evidence is tied to THESE sources)
+SECONDARY_SOURCES = ("k_gdn.hip", "k_gdn_body.hpp", "k_l0g.hip", "sicn_codec.hip", "sicn_codec_ctx.inc", "sicn_gdn_internal.h")
+
+
+def kernel_source_fingerprint(sources=KERNEL_SOURCES) -> str:
     """Identifies the kernel build a PMC summary belongs to (so a stale `traffic` is never reported)."""
     h = hashlib.sha256()
-    for name in KERNEL_SOURCES:
+    for name in sources:
         h.update((ROOT / "simple_image_compression_network_amd" / "csrc" / name).read_bytes())
     return h.hexdigest()[:16]
+
+
+def bench_image_ids(rank: int, world: int, per_gpu: int):
+    """Global indices (= seeds = keys of tests/golden/bench_4k_hashes.json) of the images rank `rank` owns in a job of world * per_gpu
+    images: the documented partition, image i -> rank i mod world (dist.shard_indices)."""
+    from simple_image_compression_network_amd.dist import shard_indices
+    return shard_indices(world * per_gpu, rank, world)
 
 
 class ClockPowerSampler:
@@ -137,8 +149,13 @@ def device_identity(torch, dev) -> str:
     devices took part in an N-rank run."""
     import socket
     p = torch.cuda.get_device_properties(dev)
-    bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
     uuid = str(getattr(p, "uuid", "")) if hasattr(p, "uuid") else ""
+    if hasattr(p, "pci_bus_id"):
+        bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, getattr(p, "pci_device_id", 0))
+    else:   # a torch without the pci_* properties: never a constant (every rank would look like the same device and an nccl run would be
+        # refused): the device's index as this process sees it + the visibility mask that maps it to a physical GPU (ADVICE r4)
+        idx = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+        bdf = "index%d/visible=%s" % (idx, os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", "all")))
     return f"{socket.gethostname()}|{bdf}|{uuid}"
 
 
@@ -345,7 +362,9 @@ def main():
 
     W, H, B = args.width, args.height, args.images_per_gpu
     # synthetic inputs: uint8 NHWC, i.i.d. uniform 0..255, one seed per global image index
-    host = np.stack([np.random.default_rng(rank * B + i).integers(0, 256, (H, W, 3), dtype=np.uint8) for i in range(B)])
+    # partition: the job's world * B images are dealt out as in dist.shard_indices / DESIGN.md section 6 (image i -> rank i mod world)
+    image_ids = bench_image_ids(rank, world, B)
+    host = np.stack([np.random.default_rng(i).integers(0, 256, (H, W, 3), dtype=np.uint8) for i in image_ids])
     x = torch.from_numpy(host).to(dev)
     # weights: rank 0's PARAM tables, replicated with one broadcast (no-op on one GPU)
     params = api.load_param_weights()
@@ -454,7 +473,7 @@ def main():
     golden = json.loads(golden_path.read_text()) if golden_path.exists() else {}
     verdict = 1   # 1 = all equal, 0 = a mismatch, -1 = no golden entry for some image (or a non-default size)
     for i in range(B):
-        g = golden.get(str(rank * B + i)) if (W, H) == (3840, 2160) else None
+        g = golden.get(str(image_ids[i])) if (W, H) == (3840, 2160) else None
         if g is None:
             verdict = min(verdict, -1) if verdict != 0 else 0
             continue
@@ -512,7 +531,28 @@ def main():
         guarded(hc.check)
         direct = torch.empty_like(out)
         hc.main.forward(x, direct, want_latent=False)      # the same transform without the coders in between
-        return {"value": round(world * B * W * H * hsteps / hdt / 1e6, 2), "unit": "Mpixels/s",
+        # the TIMED run's products against hashes the ORACLE made for the same images (tests/golden/make_hyper_hashes.py through
+        # oracle/hyper_pipeline.py): latent, both containers byte for byte, reconstruction (VERDICT r4 item 2 iii: the leg used to be
+        # compared with itself only).  Entries exist for images 0 .. 7 at 3840 x 2160; anything else reports None.
+        hg_path = ROOT / "tests" / "golden" / "hyper_4k_hashes.json"
+        hgold = json.loads(hg_path.read_text()) if hg_path.exists() else {}
+        zs_h, ys_h = hc.z_coder.sizes(), hc.y_coder.sizes()
+        oracle_ok, checked = None, []
+        if (W, H) == (3840, 2160) and hgold.get("gdn_spec_version") == 2:
+            sha = lambda t: hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()
+            for k, gid in enumerate(image_ids):
+                g = hgold.get(str(gid))
+                if g is None:
+                    continue
+                same = (sha(hc.y[k]) == g["y"] and zs_h[k] == g["z_bytes"] and ys_h[k] == g["y_bytes"]
+                        and sha(hc.z_coder.slots[k, :zs_h[k]]) == g["z_container"] and sha(hc.y_coder.slots[k, :ys_h[k]]) == g["y_container"]
+                        and sha(out_h2[k]) == g["recon"])
+                checked.append(gid)
+                oracle_ok = same if oracle_ok is None else (oracle_ok and same)
+        return {"containers_and_outputs_equal_oracle": oracle_ok, "oracle_checked_images": checked,
+                "oracle_check": "sha256 of latent, z container, y container and reconstruction of the timed run vs tests/golden/hyper_4k_hashes.json "
+                                "(oracle/hyper_pipeline.py; GDN specification version 2)",
+                "value": round(world * B * W * H * hsteps / hdt / 1e6, 2), "unit": "Mpixels/s",
                  "ms_per_step": round(hdt / hsteps * 1e3, 3), "steps": hsteps,
                  "bits_per_pixel": round(8.0 * sum(hc.bytes_per_image()) / (B * W * H), 4),
                  "round_trip_exact": bool(torch.equal(hc.y_hat, hc.y)) and bool(torch.equal(out_h2, direct)),
@@ -665,7 +705,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
         "data": "synthetic", "config": {"workload": f"{B} x {W}x{H} RGB uint8 images per GPU, eight_layers_net (PARAM weights), "
                                                     f"BASELINE.json configs[3] shard; transform only (the reference has no coder)",
-                                        "images_per_gpu": B, "global_images": world * B, "parallelism": f"image-sharded x{world}"},
+                                        "images_per_gpu": B, "global_images": world * B, "parallelism": f"image-sharded x{world}",
+                                        "partition": "image i -> rank i mod world (dist.shard_indices)", "image_ids_rank0": image_ids},
         "output_bit_exact": (None if any(v < 0 for v in verdicts) and all(v != 0 for v in verdicts) else all(v == 1 for v in verdicts)),
         "output_check": "sha256 of every latent and reconstruction of the timed run vs tests/golden/bench_4k_hashes.json (oracle direct form)",
         "rank_checksums": rank_checksums,
@@ -673,6 +714,7 @@ def main():
         "world_size": (dist.get_world_size() if use_dist else 1),
         "clocks": {"timed": clk_t, "layers": clk_l, "sustained": clk_s},
         "roofline": roof, "layers": layers,
+        "kernel_source_fingerprint": fp, "secondary_source_fingerprint": kernel_source_fingerprint(SECONDARY_SOURCES),
         "device_ms_sum_per_step": round(sum(avg_ms), 3),
         "whole_net_mfma_frac": round(net_ops / (dt / args.steps) / 1e12 / PEAK_INT8_TOPS, 4),
         # SURVEY.md 8(d), the memory view: layer-wise algorithmic bytes (every activation written once and read once)

@@ -5,17 +5,22 @@
  * PassThrough, Threshold and ChannelWise only, and the net's non-linearity is the sign-bit ReLU of
  * conv_nonsquare_top.cpp:273-275 / 189-191.  A layer given a `sicn_gdn` runs exactly the reference layer up to and
  * including the bias add (conv_nonsquare_top.cpp:272) and then applies this activation INSTEAD of that ReLU.
- * Parity status: UNPINNED (own specification: oracle/sicn_gdn_oracle.c, restated here):
+ * Parity status: UNPINNED (own specification, VERSION 2 since library 0.3: oracle/sicn_gdn_oracle.c, restated here; version 1 —
+ * floor(2^16 / sqrt(n)) to 16 absolute bits, an arithmetic shift, x clamped at -127 — produced different bytes and is gone):
  *
- *   per pixel, C channels, v = the 8-bit lane after the bias add read as int8:
- *     x_i = max(v_i, -127)
- *     n_i = beta_i + sum_j gamma[i][j] * x_j^2                 beta in [1, 65535], gamma in [0, 127]
- *     GDN  (inverse = 0):  r_i = floor(2^16 / sqrt(n_i)) = max{ r : r^2 * n_i <= 2^32 }
- *     IGDN (inverse = 1):  r_i = floor(2^8  * sqrt(n_i)) = max{ r : r^2 <= n_i * 2^16 }
- *     y_i = clamp((x_i * r_i + 2^(shift-1)) >> shift, -128, 127)   (arithmetic shift), stored as y_i mod 256
+ *   per pixel, C channels, v = the 8-bit lane after the bias add:
+ *     x_i  = int8(v_i)
+ *     n_i  = beta_i + sum_j gamma[i][j] * x_j^2                beta in [1, 65535], gamma in [0, 127]          (exact integer)
+ *     nq_i = n_i rounded to 24 significant bits (nearest-even), cut to its top 11 significant bits
+ *     GDN  (inverse = 0):  r_i = trunc11(2^(16-shift) (1 +  5 * 2^-16) / sqrt(nq_i))     trunc11: the exact real number cut to
+ *     IGDN (inverse = 1):  r_i = trunc11(2^( 8-shift) (1 + 33 * 2^-16) * sqrt(nq_i))     11 significant bits, towards zero
+ *     u_i  = x_i * r_i + 128 rounded once to IEEE binary32 (nearest-even): one fused multiply-add
+ *     y_i  = clamp(nearest-even integer of u_i, 0, 255) - 128, stored as y_i mod 256
  *
- * All integer, bit-exact by definition.  With beta / gamma read as Q8 (256 = 1.0) shift = 12 is the textbook
- * y = x / sqrt(beta + sum gamma x^2) (GDN) or y = x * sqrt(...) (IGDN).
+ * A pure function of integers: every step is an exact integer operation, a correctly rounded IEEE-754 operation, or a root needed
+ * to 11 bits whose rounding bias (5 / 33) keeps all 2048 possible nq mantissas >= 7.5 binary32 ulps from a step of trunc11, so a
+ * 1-ulp hardware root decides every case the same way (sicn_gdn_selftest_roots proves it on the device for every n).  With beta /
+ * gamma read as Q8 (256 = 1.0) shift = 12 is the textbook y = x / sqrt(beta + sum gamma x^2) (GDN) or y = x * sqrt(...) (IGDN).
  *
  * Pointers are DEVICE pointers unless named *_host.  Launch functions only enqueue on hip_stream.
  */
@@ -55,12 +60,15 @@ int sicn_deconv522_gdn(const sicn_layer_desc *desc, const sicn_weights *w, const
 int sicn_net_create_gdn(const sicn_layer_desc *descs, sicn_weights *const *weights, const sicn_gdn *const *gdn,
                         int n_layers, const sicn_options *opt, sicn_net **out);
 
-/* Test hook: the kernels' two integer roots — floor(2^16 / sqrt(n)) (inverse = 0) and floor(2^8 sqrt(n)) (inverse = 1), which
- * the device code gets from a float estimate and an integer fix-up — against integer bisection, on the device, for every
- * n in [n_begin, n_begin + count).  Synchronous.  Returns the number of n whose root differs (0 = exact), < 0 on error. */
+/* 2: the specification above.  Encoder and decoder of a hyperprior bitstream must agree on it (the bytes a version-1 library produced
+ * differ). */
+int sicn_gdn_spec_version(void);
+
+/* Test hook: r = trunc11((1 + b 2^-16) / sqrt(nq)) (inverse = 0) or trunc11((1 + b 2^-16) sqrt(nq)) (inverse = 1) exactly as the kernels
+ * compute it (one root instruction, one multiply, two masks) against the defining integer inequalities, on the device, for every n in
+ * [n_begin, n_begin + count) (n = 0 skipped), n_begin + count <= 2^31.  Synchronous.  Returns the number of n whose root differs
+ * (0 = exact), < 0 on error. */
 long long sicn_gdn_selftest_roots(int inverse, uint32_t n_begin, unsigned long long count);
-/* The same for the two-test form of floor(2^8 sqrt(n)) that the MFMA kernels (C <= 192: n < 2^29) use; n_begin + count <= 2^29. */
-long long sicn_gdn_selftest_roots_narrow(uint32_t n_begin, unsigned long long count);
 
 #ifdef __cplusplus
 }

@@ -129,21 +129,81 @@ def layer_preact_ref(x: np.ndarray, w: np.ndarray, bias: np.ndarray, transposed:
     return ((acc + bias.astype(np.int64)[None, None, :]) & 0xFF).astype(np.uint8)
 
 
-def gdn_ref(lanes: np.ndarray, beta: np.ndarray, gamma: np.ndarray, inverse: bool, shift: int) -> np.ndarray:
-    """Second, independent statement of the fixed-point GDN / IGDN of oracle/sicn_gdn_oracle.c (parity unpinned —
-    the reference has no GDN): exact Python-integer square roots (math.isqrt) instead of the C file's bisection.
-        x = max(int8(v), -127); n_i = beta_i + sum_j gamma[i][j] x_j^2
-        GDN : r = isqrt(2^32 // n)  (= max{r : r^2 n <= 2^32});   IGDN: r = isqrt(n << 16)
-        y = clamp((x r + 2^(shift-1)) >> shift, -128, 127) mod 256"""
+GDN_BIAS = (5, 33)          # r = trunc11(root * 2^s * (1 + GDN_BIAS[inverse] * 2^-16)), oracle/sicn_gdn_oracle.c
+GDN_N_BITS = 11             # significant bits of nq
+GDN_R_BITS = 11             # significant bits of r
+
+
+def _rne_shift(v: int, sh: int) -> int:
+    """v / 2^sh rounded to the nearest integer, ties to even (v >= 0, sh >= 0)."""
+    if sh == 0:
+        return v
+    q, rem, half = v >> sh, v & ((1 << sh) - 1), 1 << (sh - 1)
+    return q + (1 if rem > half or (rem == half and q & 1) else 0)
+
+
+def gdn_quantise_n(n: int) -> Tuple[int, int]:
+    """nq = n rounded to 24 significant bits (ties to even), cut to its top 11: returns (m, e), nq = m 2^e, 1024 <= m < 2048."""
+    length = n.bit_length()
+    if length > 24:
+        n = _rne_shift(n, length - 24) << (length - 24)     # may carry into bit `length`: still a multiple of 2^(length-24)
+        length = n.bit_length()
+    e = length - GDN_N_BITS
+    return (n >> e, e) if e >= 0 else (n << -e, e)
+
+
+def gdn_root(m: int, e: int, inverse: bool, shift: int) -> Tuple[int, int]:
+    """r = trunc11(2^s (1 + b 2^-16) / sqrt(nq)) (GDN, s = 16 - shift) or trunc11(2^s (1 + b 2^-16) sqrt(nq)) (IGDN, s = 8 - shift)
+    for nq = m 2^e, as (M, k): r = M 2^k, 1024 <= M < 2048.  Exact: floor(V 2^T) = isqrt(floor(V^2 4^T)) and a floor of a floor."""
     import math
+    t = 64
+    b2 = (65536 + GDN_BIAS[1 if inverse else 0]) ** 2
+    s = (8 if inverse else 16) - shift
+    num, den = b2, 1 << 32                                   # V^2 = num / den, built from integers only
+    if inverse:
+        num *= m
+        if e >= 0: num <<= e
+        else: den <<= -e
+    else:
+        den *= m
+        if e >= 0: den <<= e
+        else: num <<= -e
+    if s >= 0: num <<= 2 * s
+    else: den <<= -2 * s
+    v = math.isqrt((num << (2 * t)) // den)
+    length = v.bit_length()
+    return v >> (length - GDN_R_BITS), length - GDN_R_BITS - t
+
+
+def gdn_ref(lanes: np.ndarray, beta: np.ndarray, gamma: np.ndarray, inverse: bool, shift: int) -> np.ndarray:
+    """Second, independent statement of the fixed-point GDN / IGDN v2 of oracle/sicn_gdn_oracle.c (parity unpinned — the
+    reference has no GDN), in integers only: the roots by math.isqrt on big integers, the binary32 fused multiply-add and the
+    nearest-even conversion restated as integer roundings (the C file uses fmaf / nearbyintf and a 128-bit bisection).
+        x = int8(v); n_i = beta_i + sum_j gamma[i][j] x_j^2; nq = top 11 bits of (n rounded to 24 bits)
+        r = trunc11(root(nq) 2^s (1 + b 2^-16));  u = round24(x r + 128);  y = clamp(round(u), 0, 255) - 128   (mod 256)"""
     c = lanes.shape[-1]
-    x = np.maximum(lanes.reshape(-1, c).view(np.int8).astype(np.int64), -127)
+    x = lanes.reshape(-1, c).view(np.int8).astype(np.int64)
     n = beta.astype(np.int64)[None, :] + (x * x) @ gamma.astype(np.int64).T
-    flat = n.reshape(-1)
-    r = np.fromiter((math.isqrt(int(v) << 16) if inverse else math.isqrt((1 << 32) // int(v)) for v in flat), dtype=np.int64,
-                    count=flat.size).reshape(n.shape)
-    t = (x * r + (1 << (shift - 1))) >> shift
-    return (np.clip(t, -128, 127) & 0xFF).astype(np.uint8).reshape(lanes.shape)
+    uniq, inv = np.unique(n.reshape(-1), return_inverse=True)
+    roots = [gdn_root(*gdn_quantise_n(int(v)), inverse, shift) for v in uniq]
+    big_m = np.array([r[0] for r in roots], np.int64)[inv].reshape(n.shape)
+    k = np.array([r[1] for r in roots], np.int64)[inv].reshape(n.shape)
+    p = x * big_m                                            # |p| < 2^19; the exact value is p 2^k + 128
+    out = np.empty(n.shape, np.int64)
+    pos = k >= 0                                             # an integer: below 2^24 it is exact, above it the clamp decides
+    out[pos] = np.clip((p[pos] << k[pos]) + 128, 0, 255)
+    s = -k[~pos]
+    v = p[~pos] + (np.int64(128) << s)                       # in units of 2^-s, < 2^43
+    neg = v <= 0
+    v = np.where(neg, 1, v)
+    length = np.frexp(v.astype(np.float64))[1].astype(np.int64)   # bit length (exact below 2^53)
+    d = np.maximum(length - 24, 0)                           # first rounding: to 24 significant bits
+    q, rem, half = v >> d, v & ((np.int64(1) << d) - 1), (np.int64(1) << d) >> 1
+    v = (q + ((d > 0) & ((rem > half) | ((rem == half) & (q & 1 == 1))))) << d
+    q, rem, half = v >> s, v & ((np.int64(1) << s) - 1), np.int64(1) << (s - 1)   # second rounding: to an integer (s >= 1)
+    y = q + ((rem > half) | ((rem == half) & (q & 1 == 1)))
+    out[~pos] = np.where(neg, 0, np.clip(y, 0, 255))
+    return ((out - 128) & 0xFF).astype(np.uint8).reshape(lanes.shape)
 
 
 Params = Sequence[Tuple[np.ndarray, np.ndarray, int]]   # (W[o][ky][kx][c], bias[o], transposed)

@@ -94,7 +94,7 @@ GDN_ABI = {
     "sicn_deconv522_gdn": (_i, [_descp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(COptions), _vp]),
     "sicn_net_create_gdn": (_i, [_descp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, ctypes.POINTER(COptions), ctypes.POINTER(_vp)]),
     "sicn_gdn_selftest_roots": (ctypes.c_longlong, [_i, ctypes.c_uint32, ctypes.c_ulonglong]),
-    "sicn_gdn_selftest_roots_narrow": (ctypes.c_longlong, [ctypes.c_uint32, ctypes.c_ulonglong]),
+    "sicn_gdn_spec_version": (_i, []),
 }
 
 _u32 = ctypes.c_uint32

@@ -123,7 +123,9 @@ class LatentCoder:
                  device="cuda", stream_symbols=None):
         """stream_symbols: None or "auto" = `auto_stream_symbols` of ONE image's latent (16384 for large latents, 8192 below 2 M
         symbols), or a power of two 1024 .. 16384 (sicn_codec_*_async_sl: shorter streams = shorter critical path on small latents,
-        260 bytes per extra stream).  A decoder object must be built with the encoder's value (the container header carries it)."""
+        260 bytes per extra stream).  A decoder object must be built with the encoder's value — the container header carries it:
+        `LatentCoder.for_containers(slots, n)` builds the matching decoder for containers made elsewhere (e.g. by the C entry points
+        without `_sl`, which always write 16384-symbol streams, or by another stream length on the encoder's side)."""
         import torch
         L = _lib.lib()
         self.shape = (int(n_images), int(lat_h), int(lat_w), int(lat_c))
@@ -138,6 +140,22 @@ class LatentCoder:
         self.ws = torch.empty(max(L.sicn_codec_batch_workspace_bytes_sl(n, n_images, self.stream_symbols), 256), dtype=torch.uint8, device=dev)
         self.enc_status = torch.zeros((n_images, 2), dtype=torch.int32, device=dev)   # sicn_codec_status {error, bytes}
         self.dec_status = torch.zeros((n_images, 2), dtype=torch.int32, device=dev)
+
+    @classmethod
+    def for_containers(cls, slots, device=None):
+        """A decoder for n rANS-W containers that came from somewhere else: shape and stream length are READ from the first
+        container's 48-byte header (sicn_codec_parse_header), so a default-constructed LatentCoder — whose stream length is the
+        per-image automatic one — is never pointed at containers of another length (the decode would report status bit 2).
+        slots: CUDA uint8 [n][slot_bytes].  One small device-to-host copy (the header), once."""
+        info = parse_header(bytes(slots[0, :48].cpu().numpy().tobytes()))
+        if int(info.mode) != RANSW:
+            raise ValueError(f"container mode {int(info.mode)} is not rANS-W")
+        coder = cls(int(slots.shape[0]), int(info.lat_h), int(info.lat_w), int(info.lat_c), int(info.image_width), int(info.image_height),
+                    device=device if device is not None else slots.device, stream_symbols=int(info.stream_symbols))
+        if int(slots.shape[1]) < coder.slot:   # the writer sized its slots for its own stream length; ours can only be equal or smaller
+            raise ValueError(f"slots of {int(slots.shape[1])} bytes are shorter than the {coder.slot} bytes a container of this shape may take")
+        coder.slot = int(slots.shape[1])
+        return coder
 
     def encode(self, latents, stream=None):
         """latents: CUDA uint8 [n][h][w][c] -> self.slots (containers), self.enc_status. Enqueue only."""

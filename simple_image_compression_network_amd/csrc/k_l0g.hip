@@ -61,7 +61,7 @@ template <bool INVERSE>
 __global__ __launch_bounds__(512, 2) void k_l0g(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int8_t *__restrict__ w_l0g,
                                                 const int8_t *__restrict__ bias, const int8_t *__restrict__ gamma_img,
                                                 const uint32_t *__restrict__ beta, int IW, int IH, int OW, int OH, int tiles_y, int ty_per,
-                                                int out_layout, int sh)
+                                                int out_layout, float kc)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *wl = smem;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void k_l0g(const uint8_t *__restrict__ in, 
 #pragma unroll
         for (int it = 0; it < 2; it++) {
             v4i y[2];
-            gdn_item<2, INVERSE>(xf[it], gl, bl, g, pos, sh, y);
+            gdn_item<2, INVERSE>(xf[it], gl, bl, g, pos, kc, y);
             const int gx = X0 + 16 * it + pos;
             const bool ok = gy < OH && gx < OW;
 #pragma unroll
@@ -189,8 +189,8 @@ hipError_t launch_l0_gdn(const LayerGeom &g, const sicn_weights &w, const sicn_g
     auto go = [&](auto kernel) -> hipError_t {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L0G_LDS);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kernel, grid, dim3(512), L0G_LDS, stream, in, out, w.d_w_l0g, w.d_bias, gdn.d_gamma_mfma, gdn.d_beta, g.IW, g.IH,
-                           g.OW, g.OH, tiles_y, cut.ty_per, out_layout, gdn.shift);
+        hipLaunchKernelGGL(kernel, grid, dim3(512), L0G_LDS, stream, in, out, w.d_w_l0g, w.d_bias, gdn.d_gamma_mfma, gdn.d_beta_mfma, g.IW, g.IH,
+                           g.OW, g.OH, tiles_y, cut.ty_per, out_layout, gdn.kc);
         return hipGetLastError();
     };
     return gdn.inverse ? go(k_l0g<true>) : go(k_l0g<false>);

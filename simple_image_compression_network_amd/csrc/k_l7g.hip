@@ -62,7 +62,7 @@ __global__ __launch_bounds__(G::WAVES * 64, G::WGS_PER_CU) void k_l7g(const uint
                                                                         const int8_t *__restrict__ w_l7, const int8_t *__restrict__ bias,
                                                                         const int8_t *__restrict__ gamma_img, const uint32_t *__restrict__ beta,
                                                                         int IW, int IH, int OW, int OH, int steps_y, int y_chunks,
-                                                                        int tiles_x, int in_layout, int sh)
+                                                                        int tiles_x, int in_layout, float kc)
 {
     constexpr int L7G_COLS = G::COLS, L7G_PITCH = G::PITCH, L7G_ROWS = G::ROWS, L7G_WAVES = G::WAVES, L7G_BLOCK_PIECES = G::BLOCK_PIECES,
                   L7G_PROLOGUE_PIECES = G::PROLOGUE_PIECES, L7G_RING_PIECES = G::RING_PIECES, L7G_RING_POS = G::RING_POS,
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(G::WAVES * 64, G::WGS_PER_CU) void k_l7g(const uint
     };
     auto activate = [&](int piece, const v4i (&xf)[2]) {
         v4i y[2];
-        gdn_item<2, INVERSE>(xf, gl, bl, kg, m, sh, y);
+        gdn_item<2, INVERSE>(xf, gl, bl, kg, m, kc, y);
         const uint32_t P = (uint32_t)(piece % L7G_RING_PIECES) * 16u + (uint32_t)m;
 #pragma unroll
         for (int J = 0; J < 2; J++)   // region J, chunk kg, stored at kg ^ ((P>>2)&3) (k_l7's swizzle)
@@ -236,7 +236,7 @@ hipError_t launch_l7_gdn(const LayerGeom &g, const sicn_weights &w, const sicn_g
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kernel, dim3((unsigned)wgs), dim3(G::WAVES * 64), G::LDS, stream, in, out, w.d_w_l7, w.d_bias, gdn.d_gamma_mfma,
-                           gdn.d_beta, g.IW, g.IH, g.OW, g.OH, steps_y, y_chunks, tiles_x, in_layout, gdn.shift);
+                           gdn.d_beta_mfma, g.IW, g.IH, g.OW, g.OH, steps_y, y_chunks, tiles_x, in_layout, gdn.kc);
         return hipGetLastError();
     };
     using Wide = L7G<64, 16, 4, false>;

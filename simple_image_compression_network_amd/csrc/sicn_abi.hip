@@ -2,6 +2,7 @@
 // reference's FixedPointWeights tile format, kernel dispatch, layer chains with caller-provided
 // workspace, per-layer hipEvent timing.  Host code only; kernels live in k_*.hip.
 #include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -131,9 +132,11 @@ extern "C" void sicn_options_init(sicn_options *opt)
     if (opt) *opt = default_options();
 }
 
-// 0.2: sicn_options.split_k (a reserved slot), sicn_net_workspace_bytes grows by the K-split scratch, sicn_codec_info.struct_bytes,
-// SICN_ENODEV for a device that is not gfx950
-extern "C" int sicn_version(void) { return 1000 * 0 + 2; }
+// 0.2: sicn_options.split_k (a reserved slot), sicn_net_workspace_bytes grows by the K-split scratch, sicn_codec_info is 44 bytes
+// (stream_symbols), SICN_ENODEV for a device that is not gfx950
+// 0.3: GDN / IGDN specification version 2 (include/sicn_gdn.h): the activation's BYTES change, sicn_gdn_selftest_roots_narrow is gone
+extern "C" int sicn_version(void) { return 1000 * 0 + 3; }
+extern "C" int sicn_gdn_spec_version(void) { return 2; }
 
 extern "C" int sicn_has_alt_kernels(void)
 {
@@ -762,6 +765,7 @@ extern "C" void sicn_gdn_free(sicn_gdn *g)
 {
     if (!g) return;
     if (g->d_beta) (void)hipFree(g->d_beta);
+    if (g->d_beta_mfma) (void)hipFree(g->d_beta_mfma);
     if (g->d_gamma) (void)hipFree(g->d_gamma);
     if (g->d_gamma_mfma) (void)hipFree(g->d_gamma_mfma);
     delete g;
@@ -788,14 +792,21 @@ extern "C" int sicn_gdn_create(int channels, int inverse, int shift, const uint3
     }
     sicn_gdn *g = new (std::nothrow) sicn_gdn();
     if (!g) return SICN_ENOMEM;
-    *g = sicn_gdn{channels, inverse, shift, nullptr, nullptr, nullptr};
+    // kc = 2^s (1 + b 2^-16), s = 16 - shift / 8 - shift, b = 5 / 33 (oracle/sicn_gdn_oracle.c): 17 significant bits, exact in binary32
+    *g = sicn_gdn{channels, inverse, shift, std::ldexp((float)(65536 + (inverse ? 33 : 5)), (inverse ? 8 : 16) - shift - 16), nullptr, nullptr, nullptr, nullptr};
     bool ok = upload(beta, (size_t)channels * 4, (int8_t **)&g->d_beta) &&
               upload(gamma, (size_t)channels * channels, &g->d_gamma);
     if (ok && (channels == 128 || channels == 192)) {
         try {
             std::vector<int8_t> img((size_t)channels * channels);
             pack_gdn_gamma(gamma, channels, img.data());
-            ok = upload(img.data(), img.size(), &g->d_gamma_mfma);
+            std::vector<uint32_t> beta_mfma((size_t)channels);   // the low digit of x^2 goes through the MFMA as lo - 128
+            for (int i = 0; i < channels; i++) {
+                uint32_t row = 0;
+                for (int j = 0; j < channels; j++) row += gamma[(size_t)i * channels + j];
+                beta_mfma[(size_t)i] = beta[i] + 128u * row;
+            }
+            ok = upload(img.data(), img.size(), &g->d_gamma_mfma) && upload(beta_mfma.data(), beta_mfma.size() * 4, (int8_t **)&g->d_beta_mfma);
         } catch (const std::bad_alloc &) { ok = false; }
     }
     if (!ok) {

@@ -5,7 +5,9 @@
 
 struct sicn_gdn {
     int channels, inverse, shift;
+    float kc;              // 2^(16 - shift) (1 + 5 2^-16) (GDN) or 2^(8 - shift) (1 + 33 2^-16) (IGDN): the root's scale and rounding bias
     uint32_t *d_beta;      // [C] natural channel order
+    uint32_t *d_beta_mfma; // [C] beta + 128 * (row sum of gamma): the MFMA kernels carry the low digit of x^2 as lo - 128; nullptr as d_gamma_mfma
     int8_t *d_gamma;       // [C][C] natural order (generic kernel)
     int8_t *d_gamma_mfma;  // permuted LDS image of k_gdn, or nullptr when C is not 128 / 192
 };
@@ -22,6 +24,6 @@ hipError_t launch_l0_gdn(const LayerGeom &g, const sicn_weights &w, const sicn_g
 hipError_t launch_l7_gdn(const LayerGeom &g, const sicn_weights &w, const sicn_gdn &gdn, const uint8_t *in, uint8_t *out, int n_images,
                          hipStream_t stream, int in_layout, const sicn_options &o, const ChipGeom &chip);
 hipError_t launch_gdn_generic(const sicn_gdn &g, uint8_t *data, long long n_pos, hipStream_t stream);
-// the kernels' two integer roots against bisection for n_begin <= n < n_begin + count, on the device
+// the kernels' root (k_gdn_body.hpp: gdn_root) against exact integers for n_begin <= n < n_begin + count, on the device
 hipError_t gdn_selftest_roots(int inverse, uint32_t n_begin, unsigned long long count, unsigned long long *mismatches);
 }  // namespace sicn

@@ -27,7 +27,7 @@ import numpy as np
 from . import api, codec
 from .config import LayerDesc
 
-__all__ = ["HyperpriorCodec", "random_gdn_params", "random_layer_params", "hyper_descs"]
+__all__ = ["HyperpriorCodec", "random_gdn_params", "random_layer_params", "hyper_descs", "hyper_parameters"]
 
 
 def random_gdn_params(rng, channels: int):
@@ -73,27 +73,39 @@ def hyper_descs(lat_w: int, lat_h: int):
     return [a0, a1], [s0, s1]
 
 
+def hyper_parameters(width: int, height: int, seed: int = 0, use_gdn: bool = True):
+    """Every seeded parameter of the configuration, host side only (numpy; no GPU): what HyperpriorCodec uploads and what a checker
+    needs to restate the pipeline (tests/golden/make_hyper_hashes.py, tests/test_hyperprior.py).  Returns a dict:
+    gdn_np [8] of None | (beta, gamma, inverse, shift); da, ds: the hyper stacks' descs; pa, ps: their (weights, bias) tables;
+    ha_np, hs_np: the same as (W[o][ky][kx][c], b).  ONE generator, drawn in this order — the order is part of the seed's meaning."""
+    rng = np.random.default_rng(seed)
+    descs = api.eight_layer_descs(width, height)
+    gdn_np = [None] * 8
+    if use_gdn:
+        for l in (0, 1, 2, 4, 5, 6):
+            beta, gamma = random_gdn_params(rng, descs[l].OFM_CH)
+            gdn_np[l] = (beta, gamma, l >= 4, 12)
+    lat_h, lat_w, _ = descs[3].out_shape
+    da, ds = hyper_descs(lat_w, lat_h)
+    pa, ha_np = zip(*[random_layer_params(rng, d) for d in da])
+    ps, hs_np = zip(*[random_layer_params(rng, d) for d in ds])
+    return {"gdn_np": gdn_np, "da": da, "ds": ds, "pa": list(pa), "ps": list(ps), "ha_np": list(ha_np), "hs_np": list(hs_np)}
+
+
 class HyperpriorCodec:
     def __init__(self, width: int, height: int, n_images: int, seed: int = 0, device="cuda", use_gdn: bool = True,
                  main_params=None, options=None, z_stream_symbols=None):
         import torch
-        rng = np.random.default_rng(seed)
         self.n, self.width, self.height = int(n_images), int(width), int(height)
         self.device = torch.device(device)
-        descs = api.eight_layer_descs(width, height)
-        self.gdn_np = [None] * 8
-        gdn = [None] * 8
-        if use_gdn:
-            for l in (0, 1, 2, 4, 5, 6):
-                beta, gamma = random_gdn_params(rng, descs[l].OFM_CH)
-                self.gdn_np[l] = (beta, gamma, l >= 4, 12)
-                gdn[l] = api.GDN(beta, gamma, inverse=l >= 4, shift=12)
+        hp = hyper_parameters(width, height, seed, use_gdn)
+        self.gdn_np = hp["gdn_np"]
+        gdn = [None if g is None else api.GDN(g[0], g[1], inverse=g[2], shift=g[3]) for g in self.gdn_np]
         self.main = api.EightLayersNet(width, height, params=main_params, device=self.device, gdn=gdn if use_gdn else None,
                                        options=options)
         lat_h, lat_w, lat_c = self.main.descs[3].out_shape
-        da, ds = hyper_descs(lat_w, lat_h)
-        pa, self.ha_np = zip(*[random_layer_params(rng, d) for d in da])
-        ps, self.hs_np = zip(*[random_layer_params(rng, d) for d in ds])
+        da, ds, pa, ps = hp["da"], hp["ds"], hp["pa"], hp["ps"]
+        self.ha_np, self.hs_np = hp["ha_np"], hp["hs_np"]
         self.h_a = api.EightLayersNet(descs=da, params=list(pa), device=self.device, options=options)
         self.h_s = api.EightLayersNet(descs=ds, params=list(ps), device=self.device, options=options)
         zh, zw, zc = da[-1].out_shape

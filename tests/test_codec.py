@@ -616,3 +616,33 @@ def test_gpu_1080p_sized_container_equals_oracle_at_the_auto_stream_length():
     assert blob == ref
     got, info = codec.decode_latent(coder.slots[0, :size].clone())
     assert int(info.stream_symbols) == 8192 and int(info.n_streams) == 192 and np.array_equal(got.cpu().numpy(), lat[0])
+
+
+@gpu
+def test_gpu_decoder_built_from_the_container_header():
+    """a default LatentCoder (automatic stream length: 8192 for a 1080p latent) cannot decode containers written with another
+    length — e.g. by the C entry points without `_sl`, which always write 16384-symbol streams: the decode reports status bit 2.
+    LatentCoder.for_containers reads shape and stream length from the header and decodes them."""
+    import torch
+    from simple_image_compression_network_amd import _lib, codec
+    rng = np.random.default_rng(77)
+    shape = (68, 120, 192)
+    lat = np.stack([_mock_latent(rng, shape, zero_frac=0.5) for _ in range(2)])
+    dev = torch.from_numpy(lat).cuda()
+    slots, sizes = codec.encode_latents(dev, 1920, 1080)                 # sicn_codec_encode_batch: the format's default length
+    assert int(codec.parse_header(bytes(slots[0, :48].cpu().numpy().tobytes())).stream_symbols) == 16384
+    dec = codec.LatentCoder.for_containers(slots)
+    assert dec.stream_symbols == 16384 and dec.shape == (2,) + shape and dec.image_wh == (1920, 1080)
+    back = torch.empty_like(dev)
+    dec.decode(back, slots=slots)
+    dec.check()
+    assert torch.equal(back, dev)
+    # and the mismatch the factory exists to prevent: the automatic decoder on the same containers
+    auto = codec.LatentCoder(2, *shape)
+    assert auto.stream_symbols == 8192
+    if auto.slot <= int(slots.shape[1]):
+        padded = torch.zeros((2, auto.slot), dtype=torch.uint8, device="cuda")
+        padded[:, :min(auto.slot, int(slots.shape[1]))] = slots[:, :auto.slot]
+        auto.decode(torch.empty_like(dev), slots=padded)
+        with pytest.raises(_lib.SicnError):
+            auto.check()

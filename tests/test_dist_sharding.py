@@ -36,6 +36,24 @@ def test_shard_indices_partition():
         shard_indices(4, 2, 2)
 
 
+def test_bench_uses_the_documented_partition():
+    """bench.py deals the job's images out exactly as dist.shard_indices / DESIGN.md section 6 say (image i -> rank i mod world), so
+    the one multi-GPU run the driver makes exercises the documented partition and looks its golden hashes up under the GLOBAL index
+    (up to round 4 rank r took the contiguous block r B .. r B + B - 1)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.bench_image_ids(0, 1, 8) == list(range(8))                      # N = 1: images 0..7, as before
+    assert bench.bench_image_ids(3, 8, 8) == [3, 11, 19, 27, 35, 43, 51, 59]     # BASELINE configs[3]: 64 images over 8 GPUs
+    for world in (2, 4, 8):
+        ids = [bench.bench_image_ids(r, world, 8) for r in range(world)]
+        assert sorted(sum(ids, [])) == list(range(8 * world)) and all(i % world == r for r, part in enumerate(ids) for i in part)
+    import json
+    golden = json.loads((ROOT / "tests" / "golden" / "bench_4k_hashes.json").read_text())
+    assert all(str(i) in golden for i in range(64))                              # every index any rank of an 8-GPU run looks up
+
+
 def test_single_process_table():
     table = run_sharded(N, _make_image, _oracle_compute)
     recon, latent = _oracle_compute(np.stack([_make_image(i) for i in range(N)]))
@@ -58,6 +76,12 @@ def _worker(rank, world, port, q):
                     t.m_weights[...] = 0
         broadcast_params(params, src=0)
         assert all(np.array_equal(t.m_weights, w) for pair, ws in zip(params, want) for t, w in zip(pair, ws))
+        # the global image indices each rank owns, all-gathered: together 0 .. N-1, rank r holding exactly the i with i mod world == r
+        mine = shard_indices(N, rank, world)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        assert everyone[rank] == mine and all(i % world == r for r, part in enumerate(everyone) for i in part)
+        assert sorted(sum(everyone, [])) == list(range(N))
         q.put((rank, run_sharded(N, _make_image, _oracle_compute)))
     finally:
         dist.destroy_process_group()

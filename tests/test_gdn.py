@@ -1,8 +1,10 @@
-"""Fixed-point GDN / IGDN (include/sicn_gdn.h).  NEW functionality without a reference counterpart
-(activations.hpp:127-224 has no GDN), parity "unpinned": the CPU tests hold the two independent statements of the
-specification together (oracle/sicn_gdn_oracle.c: integer bisection; oracle/sicn_ref.py: math.isqrt) and check its
-defining properties; the GPU tests show the HIP kernels (MFMA cross-channel sum, float estimate + integer fix-up of the
-square roots) reproduce it bit for bit — standalone, behind every layer kernel family, in every internal layout of a chain."""
+"""Fixed-point GDN / IGDN, specification version 2 (include/sicn_gdn.h).  NEW functionality without a
+reference counterpart (activations.hpp:127-224 has no GDN), parity "unpinned": the CPU tests hold the two independent statements
+of the specification together (oracle/sicn_gdn_oracle.c: 128-bit bisection over the 2048 classes of nq + the C library's fmaf /
+nearbyintf; oracle/sicn_ref.py: Python integers only), re-derive the safety margin of the rounding biases from exact integers and
+check the defining properties; the GPU tests show the HIP kernels (MFMA cross-channel sum, one hardware root + one multiply + two
+masks, fma, saturating conversion) reproduce it bit for bit — standalone, behind every layer kernel family, in every internal
+layout of a chain — and that the hardware root is exact for EVERY n."""
 import ctypes
 import re
 from pathlib import Path
@@ -33,7 +35,7 @@ def _params(rng, c, kind="random"):
 def test_two_oracle_statements_agree(c, inverse):
     rng = np.random.default_rng(c * 2 + inverse)
     x = rng.integers(0, 256, (40, c), dtype=np.uint8)
-    x[0, :] = 0x80                       # -128 is clamped to -127 before squaring
+    x[0, :] = 0x80                       # -128 (version 1 clamped it; version 2 takes it as it is: x^2 = 16384)
     x[1, :] = 0x7F
     x[2, :] = 0
     for kind in ("random", "unit", "extreme"):
@@ -43,18 +45,54 @@ def test_two_oracle_statements_agree(c, inverse):
             assert np.array_equal(a, sicn_ref.gdn_ref(x, beta, gamma, inverse, shift)), (kind, shift)
 
 
+def test_two_oracle_statements_agree_on_dense_single_channel_sweeps():
+    """One channel: n = beta + gamma x^2 exactly, so beta sweeps n through every small value, the powers of two and their
+    neighbours (where nq's exponent and parity change), and all 256 lanes meet every root — for every shift."""
+    rng = np.random.default_rng(11)
+    xs = np.arange(256, dtype=np.uint8).reshape(256, 1)
+    edges = np.concatenate([[(1 << k) - 1, 1 << k, (1 << k) + 1] for k in range(1, 16)])
+    betas = np.unique(np.clip(np.concatenate([np.arange(1, 2200), edges, np.arange(65000, 65536), rng.integers(1, 65536, 400)]), 1, 65535))
+    for inverse in (False, True):
+        for shift in range(1, 25):
+            for beta in betas[:: (1 if shift in (8, 12, 16) else 37)]:
+                for gam in (0, 127):
+                    b, gm = np.array([beta], np.uint32), np.array([[gam]], np.uint8)
+                    assert np.array_equal(c_oracle.gdn(xs, b, gm, inverse, shift), sicn_ref.gdn_ref(xs, b, gm, inverse, shift)), (inverse, shift, int(beta), gam)
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_rounding_bias_keeps_every_class_away_from_a_step(inverse):
+    """The reason the specification can be computed with a 1-ulp hardware root: for each of the 2 x 1024 values (exponent parity, 10
+    fraction bits) nq can take, root(nq) (1 + b 2^-16) lies >= 7.5 binary32 ulps from the next multiple of 2^-10 (relative): an error
+    of 1 ulp in the root plus 1/2 ulp in the multiply cannot move trunc11 to the other side.  Exact integers (isqrt at 2^-64)."""
+    import math
+    b = sicn_ref.GDN_BIAS[1 if inverse else 0]
+    worst = None
+    for par in range(2):
+        for frac in range(1024):
+            m = (1024 + frac) << par                                          # nq 2^10
+            num, den = ((65536 + b) ** 2 * m, 1 << 10) if inverse else ((65536 + b) ** 2 << 10, m)   # V^2 2^32
+            v = math.isqrt((num << 160) // den)                               # V 2^96, floor
+            top = v >> (v.bit_length() - 40)                                  # 40 significant bits: 2^16 units per binary32 ulp
+            pos = top & ((1 << 29) - 1)                                       # position inside a step of trunc11 (2^13 ulps)
+            margin = min(pos, (1 << 29) - pos) / 65536.0
+            worst = margin if worst is None else min(worst, margin)
+    assert worst >= 7.5, worst
+
+
 def test_specification_properties():
     rng = np.random.default_rng(5)
     c = 16
     x = rng.integers(0, 256, (200, c), dtype=np.uint8)
+    x[0, :4] = 0x80
     beta, gamma = _params(rng, c, "unit")
-    # beta = 256 (1.0 in Q8), gamma = 0, shift = 12: GDN r = floor(65536/16) = 4096 -> y = x exactly (identity)
-    y = c_oracle.gdn(x, beta, gamma, False, 12).view(np.int8)
-    assert np.array_equal(y, np.maximum(x.view(np.int8), -127))
-    # IGDN with the same parameters: r = floor(256*16) = 4096 -> identity as well
-    y = c_oracle.gdn(x, beta, gamma, True, 12).view(np.int8)
-    assert np.array_equal(y, np.maximum(x.view(np.int8), -127))
-    # odd symmetry: y(-x) = -y(x) up to the rounding offset (floor of (v + half) vs floor of (-v + half))
+    # beta = 256 (1.0 in Q8), gamma = 0, shift = 12: GDN r = trunc11(2^4 (1 + 5 2^-16) / 16) = 1 -> y = x exactly (identity, -128 included)
+    y = c_oracle.gdn(x, beta, gamma, False, 12)
+    assert np.array_equal(y, x)
+    # IGDN with the same parameters: r = trunc11(2^-4 (1 + 33 2^-16) 16) = 1 -> identity as well
+    y = c_oracle.gdn(x, beta, gamma, True, 12)
+    assert np.array_equal(y, x)
+    # odd symmetry: y(-x) = -y(x) up to the tie rule (nearest-even of u = x r + 128 on binary32's grid, finer below 128 than above)
     beta, gamma = _params(rng, c)
     xs = np.maximum(x.view(np.int8), -127)
     yp = c_oracle.gdn(xs.view(np.uint8), beta, gamma, False, 10).view(np.int8).astype(int)
@@ -133,9 +171,8 @@ def test_gpu_gdn_apply_equals_oracle(c, inverse):
 
 @gpu
 def test_gpu_gdn_square_roots_exhaustive_ranges():
-    """The kernels estimate the square roots in float and fix them up in integers: sweep n densely through the ranges
-    where float rounding could bite (small n, perfect squares +-1, the top of the range) with a 1-channel activation
-    whose n is exactly beta + gamma * x^2."""
+    """Sweep n densely through small values, perfect squares +-1 and the top of the range with a 1-channel activation whose n is
+    exactly beta + gamma * x^2 (the generic kernel: the same gdn_root / fma / conversion as the MFMA kernels)."""
     import torch
     from simple_image_compression_network_amd import api
     rng = np.random.default_rng(1)
@@ -156,19 +193,17 @@ def test_gpu_gdn_square_roots_exhaustive_ranges():
 @gpu
 @pytest.mark.parametrize("inverse", [0, 1])
 def test_gpu_gdn_roots_exact_for_every_n(inverse):
-    """sicn_gdn_selftest_roots: the float-estimate + integer-fix-up roots of the kernels against integer bisection ON THE
-    DEVICE for EVERY n the specification admits and beyond (n < 2^31; the MFMA kernels see n < 2^29, the generic one
-    n < 2^16 + 1024 * 127 * 16129 < 2^31).  0 mismatches = the kernels' arithmetic is exact, not merely exact on samples."""
+    """sicn_gdn_selftest_roots: the root exactly as the kernels compute it — v_cvt_f32_u32, a mask, v_rsq_f32 / v_sqrt_f32 (1 ulp), one
+    multiply, a mask — against the defining integer inequalities ON THE DEVICE for EVERY n the specification admits (n < 2^31; the
+    MFMA kernels see n < 2^29, the generic one n < 2^16 + 1024 * 127 * 16384 < 2^31).  0 mismatches = the hardware root never lands on
+    the wrong side of a step of trunc11, for any exponent — not merely on samples."""
     from simple_image_compression_network_amd import _lib
     L = _lib.lib()
+    assert L.sicn_gdn_spec_version() == 2
     step = 1 << 28
     for begin in range(0, 1 << 31, step):
         assert L.sicn_gdn_selftest_roots(inverse, begin, step) == 0, (inverse, begin)
     assert L.sicn_gdn_selftest_roots(inverse, 0, (1 << 31) + 1) == -22
-    if inverse:      # the two-test form the MFMA kernels use below 2^29
-        for begin in range(0, 1 << 29, step):
-            assert L.sicn_gdn_selftest_roots_narrow(begin, min(step, (1 << 29) - begin)) == 0, begin
-        assert L.sicn_gdn_selftest_roots_narrow(0, (1 << 29) + 1) == -22
 
 
 # every kernel family that can carry a GDN: l0_rgb, mfma_conv (128 and 192 out), mfma_deconv, generic (incl. the RGB-out

@@ -567,6 +567,31 @@ def test_4k_batch_windows_and_properties(api, param_words):
     assert torch.equal(out[1], out1[0]) and torch.equal(latent[1], latent1[0])
 
 
+def test_all_64_images_of_the_4k_batch_against_the_oracle_hashes(api):
+    """BASELINE.json configs[3] in full on one GPU (VERDICT r4 item 2 i): the job's 64 synthetic 4K images (seeds 0 .. 63) as the 8
+    shards an 8-GPU run deals them into — shard r = images r, r + 8, ... (dist.shard_indices) — one after the other through
+    EightLayersNet(3840, 2160) with a batch of 8, latent and reconstruction SHA-256 against EVERY entry of
+    tests/golden/bench_4k_hashes.json (oracle direct form, tests/golden/make_bench_hashes.py).  Up to round 4 only rank 0's eight
+    images had ever met GPU output."""
+    from simple_image_compression_network_amd.dist import shard_indices
+    golden = json.loads((GOLDEN / "bench_4k_hashes.json").read_text())
+    assert all(str(i) in golden for i in range(64))
+    net = api.EightLayersNet(3840, 2160)
+    out = torch.empty((8,) + net.descs[-1].out_shape, dtype=torch.uint8, device="cuda")
+    lat = torch.empty((8,) + net.descs[3].out_shape, dtype=torch.uint8, device="cuda")
+    seen = []
+    for r in range(8):
+        ids = shard_indices(64, r, 8)
+        x = np.stack([np.random.default_rng(i).integers(0, 256, (2160, 3840, 3), dtype=np.uint8) for i in ids])
+        net.forward(_dev(x), out, lat)
+        torch.cuda.synchronize()
+        o, l = out.cpu().numpy(), lat.cpu().numpy()
+        for k, i in enumerate(ids):
+            assert [_sha(l[k]), _sha(o[k])] == golden[str(i)], f"image {i} (shard {r})"
+            seen.append(i)
+    assert sorted(seen) == list(range(64))
+
+
 def test_error_codes(api):
     from simple_image_compression_network_amd import _lib
     d = eight_layer_descs(64, 32)[1]
