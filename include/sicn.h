@@ -104,17 +104,20 @@ typedef struct sicn_options {
     int32_t persistent_grid; /* 0: one workgroup per CU; n: at most n (rounded down to a multiple of the XCD count)       */
                              /*    workgroups for the wide persistent kernels — tests use it to make every workgroup    */
                              /*    walk through many tiles of a small input                                            */
-    int32_t split_k;         /* 0: automatic (grids that leave half of the CUs idle even after split_n); 1: never; > 1: always  */
-                             /*    where the form exists (the channel-split 8 x 16 kernels inside a net chain, whose workspace  */
-                             /*    holds the partial tensors) — K is split into channel-group pairs over workgroups, exact     */
-    int32_t l7_loader;       /* layer 7 (k_l7): 0 / 1: four waves, every wave requests its share of a step's rows; 2: the        */
-                             /*    loader-wave form k_l7s (a fifth wave issues all row requests)        */
-    int32_t l0_form;         /* layer 0: 0 / 1: one workgroup per run of tiles (k_l0); 2: the persistent kernel k_l0p (two      */
-                             /*    workgroups per CU walk many runs, persistent_grid caps them; measured 11 % slower) */
-    int32_t gdn_fuse;        /* layers with a sicn_gdn: 0: layer 0 with 128 channels applies its activation itself, before its  */
-                             /*    one store (k_l0g: - 0.35 ms per 8 x 4K step); 1: never (layer kernel, then k_gdn in place);   */
-                             /*    2: 0 + the 128 -> RGB layer of a chain applies the activation of the layer before it on the   */
-                             /*    way in (k_l7g: measured no faster than k_gdn + k_l7)                            */
+    /* The four forms below MEASURED A LOSS against the defaults on MI355X and are built into the ALT  */
+    /* library only (libsicn_alt.so, `make ALT=1`; sicn_has_alt_kernels() == 1), where their parity tests run.  The product library     */
+    /* (libsicn.so) answers split_k > 1, l7_loader = 2, l0_form = 2 and gdn_fuse = 2 with SICN_EINVAL.                                   */
+    int32_t split_k;         /* 0 / 1: never split K (there is no automatic K split: it measured a loss at every size); > 1 (ALT only): */
+                             /*    forced where the form exists (the channel-split 8 x 16 kernels inside a net chain, whose workspace   */
+                             /*    holds the partial tensors) — K is split into channel-group pairs over IFM_CH / 64 workgroups, exact  */
+    int32_t l7_loader;       /* layer 7 (k_l7): 0 / 1: four waves, every wave requests its share of a step's rows; 2 (ALT only): the     */
+                             /*    loader-wave form k_l7s (a fifth wave issues all row requests; 8 % slower)      */
+    int32_t l0_form;         /* layer 0: 0 / 1: one workgroup per run of tiles (k_l0); 2 (ALT only): the persistent kernel k_l0p (two    */
+                             /*    workgroups per CU walk many runs, persistent_grid caps them; measured 11 % slower)        */
+    int32_t gdn_fuse;        /* layers with a sicn_gdn: 0: layer 0 with 128 channels applies its activation itself, before its          */
+                             /*    one store (k_l0g); 1: never (layer kernel, then k_gdn in place); 2 (ALT only): 0 + the 128 -> RGB     */
+                             /*    layer of a chain applies the activation of the layer before it on the way in (k_l7g: measured no      */
+                             /*    faster than k_gdn + k_l7)                                                              */
     int32_t reserved[2];
 } sicn_options;
 

@@ -824,6 +824,12 @@ hipError_t launch_pipelined(const LayerGeom &g, const sicn_weights &w, const uin
     if ((size_t)g.IH * g.IW * g.CIN >= (size_t)OOB || (size_t)g.OH * g.OW * g.COUT >= (size_t)OOB) return hipErrorInvalidValue;
 #define SICN_P(NQ, NT, NTF, D, TX) return launch_p<NQ, NT, NTF, D, TX>(g, w, in, out, n_images, stream, in_layout, out_layout, relu, chip)
 #define SICN_PK(NQ, NT, NTF, D, TX) return launch_p<NQ, NT, NTF, D, TX, NQ / 2>(g, w, in, out, n_images, stream, in_layout, out_layout, relu, chip, ks)
+    // The K split (round 4) measured a LOSS on this chip: its instantiations live in the ALT build only (libsicn_alt.so, with
+    // their tests: tests/alt_kernels_check.py); the product library rejects sicn_options.split_k > 1 (SICN_EINVAL).
+#ifndef SICN_ALT_KERNELS
+    if (split_k > 1) return hipErrorInvalidValue;
+    (void)ks;
+#else
     if (split && tx == 16 && split_k > 1) {   // 64 output channels and one channel-group pair per workgroup (K split, round 4)
         if (split_k != g.CIN / 64) return hipErrorInvalidValue;
         if (g.transposed) {
@@ -836,6 +842,7 @@ hipError_t launch_pipelined(const LayerGeom &g, const sicn_weights &w, const uin
             if (g.CIN == 192 && g.COUT == 128) SICN_PK(6, 4, 8, false, 16);
         }
     }
+#endif
     if (split && tx == 16) {   // 64 output channels per workgroup
         if (g.transposed) {
             if (g.CIN == 128 && g.COUT == 128) SICN_P(4, 4, 8, true, 16);

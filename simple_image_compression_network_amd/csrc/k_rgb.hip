@@ -153,6 +153,8 @@ __global__ __launch_bounds__(256, 2) void k_l0(const uint8_t *__restrict__ in, u
     }
 }
 
+static_assert(L0_RAW_BYTES >= (L0_RAW_ROWS * L0_RAW_DW + 63) / 64 * 256, "k_l0: whole request instructions fit the raw buffer");
+#ifdef SICN_ALT_KERNELS   // measured 11 % slower than k_l0: ALT build only (libsicn_alt.so), the product library rejects l0_form = 2
 // ---- the PERSISTENT form of layer 0 (round 4) -------------------------------------------------------------------------------------
 // k_l0's cost model on 8 x 4K is 0.40 ms + 0.365 ms / (tiles per run): every workgroup pays a prologue — the burst that brings its
 // run's raw pixels, the weights and the bias into LDS, one memory latency, two barriers — that only the CU's other workgroup
@@ -167,7 +169,6 @@ constexpr int L0P_RAW_ROWS = 2 * L0_TY * L0P_RUN + 3;       // 115
 // the CU's other workgroup (LDS-DMA is not held to the allocation: seen as wrong outputs at 2 x 4K, never with one workgroup per CU)
 constexpr int L0P_RAW_BYTES = (L0P_RAW_ROWS * (L0_RAW_DW / 4) + 63) / 64 * 1024;
 static_assert(L0P_RAW_BYTES >= L0P_RAW_ROWS * L0_RAW_DW * 4 + 12, "the last quad over-reads 3 dwords");
-static_assert(L0_RAW_BYTES >= (L0_RAW_ROWS * L0_RAW_DW + 63) / 64 * 256, "k_l0: whole request instructions fit the raw buffer");
 // one kernel row's MFMA operands of k_l0p: NTJ weight fragments and the pixel fragments of the wave's two output rows
 template <int NTJ>
 struct L0pFrag {
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(256, 2) void k_l0p(const uint8_t *__restrict__ in, 
         rbuf ^= 1;
     }
 }
+#endif   // SICN_ALT_KERNELS: k_l0p
 
 // Test hook: sicn_options.strip_chunks = n forces the number of vertical chunks a strip is cut into (the
 // default heuristic gives small images one step per workgroup, which never exercises the rolling window).
@@ -403,6 +405,9 @@ hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
     dim3 grid((unsigned)tiles_x, (unsigned)y_chunks, (unsigned)n_images);
     if ((size_t)g.IH * g.IW * 3 * (size_t)n_images + 4 >= (size_t)OOB) return hipErrorInvalidValue;
     if ((size_t)g.OH * g.OW * g.COUT >= (size_t)OOB) return hipErrorInvalidValue;   // buffer-descriptor stores
+#ifndef SICN_ALT_KERNELS
+    if (o.l0_form == 2) return hipErrorInvalidValue;   // k_l0p: ALT build only
+#else
     // the persistent form (k_l0p): sicn_options.l0_form = 2 only.  Measured on 8 x 4K (r04, A/B in one process): 0.481 ms against
     // k_l0's 0.434 — the layer is bound by issue slots (40 MFMAs of 32 cycles + the packing per tile and wave), not by the prologue
     // the persistent form removes; DESIGN.md §3.2.  Kept as a tested alternative.
@@ -421,6 +426,7 @@ hipError_t launch_l0(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
                            runs_y, n_images, out_layout, relu ? ACT_FLOOR_RELU : ACT_FLOOR_RAW);
         return hipGetLastError();
     }
+#endif
     if (g.COUT == 128) {
         const size_t lds = 5 * 128 * KSTEP + 2 * L0_PATCH + 128 + L0_RAW_BYTES;
         hipError_t e = hipFuncSetAttribute((const void *)k_l0<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -750,6 +756,7 @@ __global__ __launch_bounds__(256, L7_WGS) void k_l7(const uint8_t *__restrict__ 
 {
     l7_body<false>(in, out, w_l7, bias, IW, IH, OW, OH, steps_y, y_chunks, tiles_x, n_images, in_layout, n_xcd);
 }
+#ifdef SICN_ALT_KERNELS   // measured 8 % slower than k_l7: ALT build only, the product library rejects l7_loader = 2
 // five waves: four consumers + the loader; three workgroups per CU = 15 waves, i.e. four on three of the SIMDs: 128 VGPRs at most
 __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_l7s(
     const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int8_t *__restrict__ w_l7, const int8_t *__restrict__ bias, int IW, int IH,
@@ -757,6 +764,7 @@ __global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 {
     l7_body<true>(in, out, w_l7, bias, IW, IH, OW, OH, steps_y, y_chunks, tiles_x, n_images, in_layout, n_xcd);
 }
+#endif
 
 #ifdef SICN_EXP_L7_STAMP
 extern "C" int sicn_debug_l7_stamps(unsigned long long *out8)   // reads and clears the sums
@@ -803,17 +811,22 @@ hipError_t launch_l7(const LayerGeom &g, const sicn_weights &w, const uint8_t *i
     // cut is the one that stays just under TWO workgroups per CU, 510 of 512; the 640 of round 2 was the middle of a flat region)
     const int y_chunks = l7_chunks(tiles_x, n_images, steps_y, o.strip_chunks, chip);
     const size_t lds = 2 * L7_REGION + 4 * L7_STAGE + 1024;
-    const bool split = o.l7_loader == 2;   // the loader-wave form (k_l7s): see l7_body; 0 / 1 = the four-wave kernel
-    const void *fn = split ? (const void *)k_l7s : (const void *)k_l7;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
     const dim3 grid(xcd_grid_size((long)tiles_x * y_chunks * n_images, chip.n_xcd));
-    if (split)
+#ifdef SICN_ALT_KERNELS
+    if (o.l7_loader == 2) {   // the loader-wave form (k_l7s): see l7_body; 0 / 1 = the four-wave kernel
+        hipError_t es = hipFuncSetAttribute((const void *)k_l7s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (es != hipSuccess) return es;
         hipLaunchKernelGGL(k_l7s, grid, dim3(320), lds, stream, in, out, w.d_w_l7, w.d_bias, g.IW, g.IH, g.OW, g.OH, steps_y, y_chunks,
                            tiles_x, n_images, in_layout, chip.n_xcd);
-    else
-        hipLaunchKernelGGL(k_l7, grid, dim3(256), lds, stream, in, out, w.d_w_l7, w.d_bias, g.IW, g.IH, g.OW, g.OH, steps_y, y_chunks,
-                           tiles_x, n_images, in_layout, chip.n_xcd);
+        return hipGetLastError();
+    }
+#else
+    if (o.l7_loader == 2) return hipErrorInvalidValue;   // k_l7s: ALT build only
+#endif
+    hipError_t e = hipFuncSetAttribute((const void *)k_l7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_l7, grid, dim3(256), lds, stream, in, out, w.d_w_l7, w.d_bias, g.IW, g.IH, g.OW, g.OH, steps_y, y_chunks,
+                       tiles_x, n_images, in_layout, chip.n_xcd);
     return hipGetLastError();
 }
 

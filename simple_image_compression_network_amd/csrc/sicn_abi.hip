@@ -63,6 +63,12 @@ const sicn_options &default_options()
         if (d.l7_loader < 0 || d.l7_loader > 2) bad("SICN_L7_LOADER", d.l7_loader);
         if (d.l0_form < 0 || d.l0_form > 2) bad("SICN_L0_FORM", d.l0_form);
         if (d.gdn_fuse < 0 || d.gdn_fuse > 2) bad("SICN_GDN_FUSE", d.gdn_fuse);
+#ifndef SICN_ALT_KERNELS   // forms that measured a loss live in the ALT build only
+        if (d.split_k > 1) bad("SICN_SPLIT_K", d.split_k);
+        if (d.l7_loader == 2) bad("SICN_L7_LOADER", d.l7_loader);
+        if (d.l0_form == 2) bad("SICN_L0_FORM", d.l0_form);
+        if (d.gdn_fuse == 2) bad("SICN_GDN_FUSE", d.gdn_fuse);
+#endif
         return d;
     }();
     return o;
@@ -123,6 +129,11 @@ static int resolve_options(const sicn_options *in, sicn_options *out)
     if (o.split_k < 0 || o.split_k > 4 || o.l7_loader < 0 || o.l7_loader > 2 || o.l0_form < 0 || o.l0_form > 2 || o.gdn_fuse < 0 ||
         o.gdn_fuse > 2)
         return SICN_EINVAL;
+#ifndef SICN_ALT_KERNELS
+    // k_l0p, k_l7s, k_l7g and the K split measured a loss against the defaults: they are built into
+    // libsicn_alt.so only, where their parity tests run (tests/alt_kernels_check.py)
+    if (o.split_k > 1 || o.l7_loader == 2 || o.l0_form == 2 || o.gdn_fuse == 2) return SICN_EINVAL;
+#endif
     *out = o;
     return SICN_OK;
 }
@@ -367,6 +378,7 @@ static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint
     if (gdn && gdn->channels != d->OFM_CH) return SICN_EINVAL;
     const LayerGeom g = geom_of(*d);
     const bool relu = gdn == nullptr;
+    if (in_gdn && layer_kernel(*d, o, gdn != nullptr) != KK_L7_RGB) return SICN_EINVAL;   // only that kernel takes one — checked BEFORE anything is enqueued
     ChipGeom chip;
     if ((rc = chip_geom(&chip)) != SICN_OK) return rc;   // no device, or not a gfx950 one
     hipError_t e;
@@ -382,8 +394,15 @@ static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint
         break;
     case KK_L7_RGB:
         // in_gdn: the input holds the previous layer's pre-activation lanes, its activation is applied on the way in (k_l7g.hip)
-        e = in_gdn ? launch_l7_gdn(g, *w, *in_gdn, in, out, n_images, stream, in_layout, o, chip)
-                   : launch_l7(g, *w, in, out, n_images, stream, in_layout, o, chip);
+#ifdef SICN_ALT_KERNELS
+        if (in_gdn) {
+            e = launch_l7_gdn(g, *w, *in_gdn, in, out, n_images, stream, in_layout, o, chip);
+            break;
+        }
+#else
+        if (in_gdn) return SICN_EINVAL;   // k_l7g: ALT build only (gdn_fuse = 2 is rejected, so no chain ever defers an activation)
+#endif
+        e = launch_l7(g, *w, in, out, n_images, stream, in_layout, o, chip);
         break;
     case KK_MFMA_CONV:
     case KK_MFMA_DECONV:
@@ -399,7 +418,6 @@ static int run_layer(const sicn_layer_desc *d, const sicn_weights *w, const uint
         break;
     default: e = launch_generic(g, *w, in, out, n_images, stream, relu); break;
     }
-    if (in_gdn && layer_kernel(*d, o, gdn != nullptr) != KK_L7_RGB) return SICN_EINVAL;   // only that kernel takes one
     if (e == hipSuccess && gdn && !defer_gdn) e = launch_gdn(*gdn, out, out_layout, d->OFM_ROW, d->OFM_COL, n_images, stream);
     if (e == hipErrorInvalidValue) return SICN_EINVAL;
     return e == hipSuccess ? SICN_OK : SICN_ENODEV;

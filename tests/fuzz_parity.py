@@ -27,6 +27,7 @@ rng = np.random.default_rng(args.seed)
 
 FAMILIES = [  # (cin, cout, simd, pe, transposed)
     (3, 128, 3, 8, 0), (128, 128, 8, 16, 0), (128, 192, 8, 24, 0), (192, 128, 12, 16, 1), (128, 128, 8, 16, 1), (128, 3, 8, 3, 1)]
+HAS_ALT = api._lib.lib().sicn_has_alt_kernels() == 1   # SICN_LIB=.../libsicn_alt.so: also draws the forms that live in the ALT build only
 bad = 0
 for case in range(args.cases):
     cin, cout, simd, pe, tr = FAMILIES[rng.integers(len(FAMILIES))]
@@ -47,7 +48,7 @@ for case in range(args.cases):
         env["tile_x"] = int(rng.choice([16, 32]))
     if rng.random() < 0.3:
         env["split_n"] = int(rng.choice([1, 2, 4]))
-    if cin == 3 and rng.random() < 0.3:      # the persistent layer-0 kernel (k_l0p), 1 .. all workgroups
+    if HAS_ALT and cin == 3 and rng.random() < 0.3:      # the persistent layer-0 kernel (k_l0p, ALT build only), 1 .. all workgroups
         env["l0_form"] = 2
         env.pop("strip_chunks", None)
         env["persistent_grid"] = int(rng.choice([1, 3, 8, 64, 0]))
@@ -138,7 +139,7 @@ for case in range(args.gdn):
         Wt = rng.integers(-8, 8, (cout, 5, 5, cin)).astype(np.int8)
         bt = rng.integers(-128, 128, cout).astype(np.int8)
         return d, Wt, bt
-    if case % 2 == 0:     # k_l0g
+    if case % 2 == 0 or not HAS_ALT:     # k_l0g (k_l7g below exists in the ALT build only)
         d, Wt, bt = mk(3, 128, 3, 8, int(rng.integers(1, 300)), int(rng.integers(1, 200)), 0)
         x = rng.integers(0, 256, (n,) + d.in_shape, dtype=np.uint8)
         g = api.GDN(beta, gamma, inverse, 12)

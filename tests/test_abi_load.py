@@ -151,16 +151,47 @@ def test_launch_planning_follows_the_chip_size_without_gpu():
     assert (_plan(d256[3], 1, 256)["split_n"], _plan(d256[4], 1, 256)["split_n"]) == (3, 2)
     p = _plan(d256[1], 1, 32)                           # 32 tiles on 32 CUs: no split
     assert (p["split_n"], p["split_k"]) == (1, 1)
-    p = _plan(d256[3], 1, 256, split_k=2)
-    assert (p["split_n"], p["split_k"], p["gz"]) == (3, 2, 2)
-    p = _plan(d256[4], 1, 256, split_k=2)               # 192 input channels: three channel-group pairs
-    assert (p["split_n"], p["split_k"], p["gz"]) == (2, 3, 3)
-    assert _plan(d1080[2], 1, 256, split_n=2, split_k=2, tile_x=16)["split_k"] == 2      # forced on a full grid
     # layer 0 runs: at most 9 tiles per workgroup, about four workgroups per CU on small images
     p0 = _plan(d4k[0], 8, 256)
     assert p0["ty_per"] <= 9 and p0["gy"] * p0["ty_per"] >= (1080 + 7) // 8
     d768 = eight_layer_descs(768, 512)
     assert _plan(d768[0], 1, 256)["gy"] == 32 and _plan(d768[0], 1, 32)["gy"] == 11
+
+
+def test_product_library_rejects_the_alt_only_forms_and_the_alt_session_runs():
+    """the kernel forms that measured a loss (k_l0p, k_l7s, k_l7g, the K split) are built into libsicn_alt.so
+    only.  The product library answers their options with SICN_EINVAL; the planning asserts that need them (below, marked `alt`)
+    run in a child pytest on the ALT library — no GPU needed for sicn_debug_plan."""
+    from conftest import run_alt_session
+    L = _lib.lib()
+    d = REFERENCE_DESCS[1].to_c()
+    out = ctypes.c_void_p()
+    plan = (ctypes.c_int32 * 12)()
+    for opt in ({"l0_form": 2}, {"l7_loader": 2}, {"gdn_fuse": 2}, {"split_k": 2}):
+        o = _lib.make_options(**opt)
+        assert L.sicn_conv2d_opt(ctypes.byref(d), None, None, None, 1, ctypes.byref(o), None) == -22, opt
+        assert L.sicn_net_create_opt(ctypes.byref(d), ctypes.byref(out), 1, ctypes.byref(o), ctypes.byref(out)) == -22, opt
+        assert L.sicn_debug_plan(ctypes.byref(d), 1, ctypes.byref(o), 256, plan) == -22, opt
+    for opt in ({"l0_form": 1}, {"l7_loader": 1}, {"gdn_fuse": 1}, {"split_k": 1}):      # "never" stays a valid request
+        o = _lib.make_options(**opt)
+        assert L.sicn_debug_plan(ctypes.byref(d), 1, ctypes.byref(o), 256, plan) == 0, opt
+    r = run_alt_session("alt and not gpu", timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+@pytest.mark.alt
+def test_alt_launch_planning_of_the_k_split_and_the_fused_rgb_layer():
+    """The launch plans of the ALT-only forms (run by the driver test above on libsicn_alt.so): the K split is never automatic and takes
+    IFM_CH / 64 slices when forced; k_l7g's strip cut."""
+    from simple_image_compression_network_amd.config import eight_layer_descs
+    assert _lib.lib().sicn_has_alt_kernels() == 1
+    d256, d1080, d4k, d768 = (eight_layer_descs(*wh) for wh in ((256, 256), (1920, 1080), (3840, 2160), (768, 512)))
+    p = _plan(d256[3], 1, 256, split_k=2)
+    assert (p["split_n"], p["split_k"], p["gz"]) == (3, 2, 2)
+    p = _plan(d256[4], 1, 256, split_k=2)               # 192 input channels: three channel-group pairs
+    assert (p["split_n"], p["split_k"], p["gz"]) == (2, 3, 3)
+    assert _plan(d1080[2], 1, 256, split_n=2, split_k=2, tile_x=16)["split_k"] == 2      # forced on a full grid
     # the RGB layer behind a layer with an activation (k_l7g, gdn_fuse = 2): strips of 62 columns, steps of 4 rows, one workgroup per
     # CU at a time; the cut = fewest step-times on the busiest CU (a cut costs about two steps), the smallest such
     def l7g_cut(iw, ih, n, n_cu):

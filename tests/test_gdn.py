@@ -263,7 +263,9 @@ def test_gpu_wide_persistent_layer_with_gdn_equals_oracle(case, inverse, grid):
 
 
 @gpu
-@pytest.mark.parametrize("options", [{}, {"gdn_fuse": 2}, {"gdn_fuse": 1}, {"gdn_fuse": 2, "no_phase_layout": 1}, {"tile_x": 16}, {"no_phase_layout": 1}, {"force_generic": 1}, {"wave_tile": 128, "persistent_grid": 8}])
+@pytest.mark.parametrize("options", [{}, pytest.param({"gdn_fuse": 2}, marks=pytest.mark.alt), {"gdn_fuse": 1},
+                                     pytest.param({"gdn_fuse": 2, "no_phase_layout": 1}, marks=pytest.mark.alt), {"tile_x": 16}, {"no_phase_layout": 1},
+                                     {"force_generic": 1}, {"wave_tile": 128, "persistent_grid": 8}])
 def test_gpu_gdn_net_all_internal_layouts(options):
     """The hyperprior-style main transform: GDN after L0-L2, IGDN after L4-L6 (L3 and L7 keep the reference's ReLU), as one
     sicn_net chain.  The activations run in place on GROUP / PHASE / NHWC intermediates; latent and reconstruction must
@@ -375,6 +377,7 @@ RGB_TAIL = [(128, 128, 8, 16, 1, 1, 1), (128, 128, 8, 16, 8, 5, 1), (128, 128, 8
             (128, 128, 8, 16, 31, 20, 1), (128, 128, 8, 16, 45, 33, 1), (128, 128, 8, 16, 63, 7, 1), (128, 128, 8, 16, 125, 17, 0)]
 
 
+@pytest.mark.alt
 @gpu
 @pytest.mark.parametrize("case", RGB_TAIL)
 @pytest.mark.parametrize("inverse", [False, True])
@@ -403,6 +406,7 @@ def test_gpu_rgb_layer_applies_previous_gdn_equals_oracle(case, inverse):
     assert np.array_equal(tap[1].cpu().numpy(), c_oracle.gdn(pre, beta, gamma, inverse, 12))
 
 
+@pytest.mark.alt
 @gpu
 def test_gpu_rgb_layer_applies_previous_gdn_at_1080p_input():
     """One workgroup of 1024 threads on every CU, 16 strips x 135 steps cut by sicn_plan.h: 960 x 540 -> (IGDN) -> 1920 x 1080 x 128 -> RGB 3840 x 2160,

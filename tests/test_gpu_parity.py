@@ -133,6 +133,24 @@ def test_alt_build_32x32x32_kernels(api):
     assert "alt kernels ok" in r.stdout
 
 
+def test_alt_build_measured_loss_kernels(api):
+    """k_l0p (l0_form = 2), k_l7s (l7_loader = 2), k_l7g (gdn_fuse = 2) and the K split (split_k > 1) measured a loss against the
+    defaults and live in libsicn_alt.so only: the product library rejects their
+    options with SICN_EINVAL, and their parity tests — every test marked `alt` in this directory — run here, in a child pytest
+    whose library is the ALT build, so they stay bit-exact without being product surface."""
+    from conftest import run_alt_session
+    L = api._lib.lib()
+    d = _mk_desc(128, 128, 8, 16, 8, 8, 0).to_c()
+    out = ctypes.c_void_p()
+    for opt in ({"l0_form": 2}, {"l7_loader": 2}, {"gdn_fuse": 2}, {"split_k": 2}, {"split_k": 3}):
+        o = api._lib.make_options(**opt)
+        assert L.sicn_conv2d_opt(ctypes.byref(d), None, None, None, 1, ctypes.byref(o), None) == -22, opt
+        assert L.sicn_net_create_opt(ctypes.byref(d), ctypes.byref(out), 1, ctypes.byref(o), ctypes.byref(out)) == -22, opt
+    r = run_alt_session("alt and gpu")
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-1000:]
+
+
 @pytest.mark.parametrize("prefetch", [1, 2])
 @pytest.mark.parametrize("tile_x", ["16", "32"])
 @pytest.mark.parametrize("case", MFMA_CASES + [(128, 128, 8, 16, 50, 20, 0), (192, 128, 12, 16, 37, 21, 1), (128, 192, 8, 24, 47, 18, 0),
@@ -194,6 +212,7 @@ KSPLIT_CASES = MFMA_CASES + [(128, 128, 8, 16, 50, 20, 0), (192, 128, 12, 16, 37
                              (128, 128, 8, 16, 1, 1, 0), (192, 128, 12, 16, 1, 1, 1), (128, 192, 8, 24, 16, 8, 0)]
 
 
+@pytest.mark.alt
 @pytest.mark.parametrize("case", KSPLIT_CASES)
 def test_k_split_matches_oracle(api, case):
     """K split (round 4): the channel-group pairs of a layer over 2 / 3 workgroups, every slice stores its
@@ -220,6 +239,7 @@ def test_k_split_matches_oracle(api, case):
     assert np.array_equal(got, same)
 
 
+@pytest.mark.alt
 def test_k_split_scratch_needs_no_initialisation_and_cleans_up(api):
     """The K-split arrival words live in the caller's workspace, which nobody initialises: whatever it holds — zeros, 0xFF,
     random bytes, the leftovers of earlier launches — reads as "nobody has arrived" unless it carries the net's random 56-bit
@@ -258,6 +278,7 @@ def test_k_split_scratch_needs_no_initialisation_and_cleans_up(api):
         assert np.array_equal(out.cpu().numpy(), ref)
 
 
+@pytest.mark.alt
 @pytest.mark.parametrize("size", [(768, 512, "rng768"), (256, 256, "rng256")])
 def test_k_split_in_chain(api, size):
     """The whole net with the K split forced wherever the form exists (layers 1 - 6 at 8 x 16 tiles)."""
@@ -853,6 +874,7 @@ def test_crop_nhwc_one_launch(api, shape):
     assert _lib.lib().sicn_crop_nhwc(ctypes.c_void_p(d_src.data_ptr()), ctypes.c_void_p(d_dst.data_ptr()), n, hs, ws, hs + 1, w, c, None) == -22
 
 
+@pytest.mark.alt
 @pytest.mark.parametrize("chunks", [0, 1, 3])
 @pytest.mark.parametrize("case", [(128, 3, 8, 3, 70, 45, 1), (128, 3, 8, 3, 64, 32, 1), (128, 3, 8, 3, 1, 1, 1), (128, 3, 8, 3, 33, 7, 1), (128, 3, 8, 3, 96, 130, 1)])
 def test_layer7_loader_wave_form_matches_oracle(api, case, chunks):
@@ -868,6 +890,7 @@ def test_layer7_loader_wave_form_matches_oracle(api, case, chunks):
         assert np.array_equal(got[i], sicn_ref.deconv522_ref(x[i], W, b)), i
 
 
+@pytest.mark.alt
 def test_layer7_loader_wave_form_in_chain(api):
     xin = _dev(_input("rng768")[None])
     net = api.EightLayersNet(768, 512, options={"l7_loader": 2})
@@ -876,6 +899,7 @@ def test_layer7_loader_wave_form_in_chain(api):
     assert _sha(out[0].cpu().numpy()) == HASHES["layers"]["rng768"][7]
 
 
+@pytest.mark.alt
 @pytest.mark.parametrize("grid", [0, 1, 3, 8])
 @pytest.mark.parametrize("case", [(3, 128, 3, 8, 140, 150, 0), (3, 128, 3, 8, 64, 48, 0), (3, 128, 3, 8, 2, 2, 0), (3, 128, 3, 8, 70, 290, 0), (3, 128, 3, 8, 513, 31, 0)])
 def test_layer0_persistent_form_matches_oracle(api, case, grid):
@@ -892,6 +916,7 @@ def test_layer0_persistent_form_matches_oracle(api, case, grid):
     assert np.array_equal(got, _run_layer(api, d, words, b, x, l0_form=1))
 
 
+@pytest.mark.alt
 def test_layer0_persistent_form_in_chain(api):
     xin = _dev(np.stack([_input("rng768"), _input("ones768")]))
     net = api.EightLayersNet(768, 512, options={"l0_form": 2, "persistent_grid": 16})
@@ -902,6 +927,7 @@ def test_layer0_persistent_form_in_chain(api):
         assert _sha(latent[i].cpu().numpy()) == HASHES["layers"][name][3]
 
 
+@pytest.mark.alt
 def test_layer0_persistent_form_two_workgroups_per_cu(api):
     """3 x 1080p = 900 runs: 512 workgroups, two on every CU, most with two runs.  (The first build of k_l0p sized its raw buffers
     by rows, and the idle lanes of the last request instruction wrote zeros past the workgroup's LDS — into the weights of the

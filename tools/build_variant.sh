@@ -14,7 +14,9 @@ if [ $# -eq 0 ]; then
   make -C "$CSRC" -j4 ARCH=gfx950 OBJDIR="$OUT" OUT="$OUT/libsicn.so" EXTRA="$FLAGS" >/dev/null
 else
   rm -f "$OUT"/*.o
-  for o in sicn_abi sicn_codec sicn_convlayer k_generic k_mfma16 k_mfma16x k_mfma16p k_rgb k_gdn; do cp "$CSRC/$o.o" "$OUT"/; done
+  # every object of the product build (the Makefile's SRCS, whatever they are this round: a fixed list once missed k_l0g / k_l7g and the
+  # variant failed at dlopen with undefined symbols)
+  for o in $(make -s -C "$CSRC" print-objs); do cp "$CSRC/$o" "$OUT"/; done
   for f in "$@"; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter $FLAGS -c "$CSRC/$f" -o "$OUT/${f%.hip}.o" &
     pids="$pids $!"

@@ -44,3 +44,30 @@ for slot, layer in enumerate((1, 2, 6, 5)):
     print(f"layer {layer}: {ms[layer] / max(cnt[layer], 1):.3f} ms; {len(s)} workgroups x {tiles.mean():.1f} tiles; "
           f"{(cyc / tiles).mean():.0f} cycles per tile, hand-over pass {(hand / tiles).mean():.0f}; clock {np.median(clk):.2f} GHz; "
           f"spans p5 {np.percentile(cyc, 5):.0f} p50 {np.percentile(cyc, 50):.0f} max {cyc.max():.0f}")
+
+# ---- round 5: where layer 5's "8 % per tile" against layer 6 (and layer 2's against layer 1) comes from -------------------------------------
+# The same kernel walks 8 tiles per workgroup in layers 2 / 5 and 32 in layers 1 / 6.  Model: launch-to-end time = a + b * (tiles per workgroup);
+# b from the pair of layers, a = what a launch costs beyond its tiles (launch latency, the first tile's un-overlapped patch + ring fill, the last
+# hand-over and the drain).  The stamps give the same split from inside: a workgroup's own span against tiles * (cycles per tile of the long layer),
+# and the start-to-end window of all workgroups against the layer's event time.
+def fit(short, long_):
+    (ms_s, t_s), (ms_l, t_l) = short, long_
+    b = (ms_l - ms_s) / (t_l - t_s)
+    return b, ms_s - b * t_s
+per = {}
+for slot, layer in enumerate((1, 2, 6, 5)):
+    s = allr[slot]
+    s = s[s[:, 0] > 0]
+    if len(s):
+        start, ticks = s[:, 4], s[:, 1]
+        window_us = ((start + ticks).max() - start.min()) / 100.0
+        per[layer] = (ms[layer] / max(cnt[layer], 1), s[:, 2].mean(), (s[:, 0] / s[:, 2]).mean(), window_us, (start.max() - start.min()) / 100.0)
+for short, long_, name in ((2, 1, "conv"), (5, 6, "deconv")):
+    if short in per and long_ in per:
+        b, a = fit(per[short][:2], per[long_][:2])
+        print(f"{name}: layer {long_} {per[long_][0]:.3f} ms / {per[long_][1]:.1f} tiles per workgroup, layer {short} {per[short][0]:.3f} ms / {per[short][1]:.1f}:  "
+              f"time = {a * 1e3:.1f} us + {b * 1e3:.2f} us per tile;  the fixed part is {100 * a / per[short][0]:.1f} % of layer {short} and "
+              f"{100 * a / per[long_][0]:.1f} % of layer {long_}")
+        for l in (long_, short):
+            print(f"   layer {l}: cycles per tile inside the workgroups {per[l][2]:.0f}; all workgroups' window {per[l][3]:.1f} us of the event's {per[l][0] * 1e3:.1f} us "
+                  f"(starts spread over {per[l][4]:.1f} us)")
