@@ -582,12 +582,12 @@ static int64_t wrap_bits(int64_t v, int bits, int is_signed)
     return (int64_t)u;
 }
 
-/* out: uint32 per lane = the low OUT_BIT bits of the activation result */
+/* in: one byte per lane (low IN_BIT bits = the lane); out: uint32 per lane = the low OUT_BIT bits of the activation result */
 int sicn_or_convlayer_dataflow(const sicn_or_convlayer_desc *d, const uint64_t *m_weights /* [PE][TILES] */,
                                const int32_t *thresholds /* [PE][NF][NUM_TH] or NULL */, const uint8_t *in,
                                uint32_t *out, int use_fsm)
 {
-    if (d->IFM_CH % d->SIMD || d->OFM_CH % d->PE || d->OFM_DIM != d->IFM_DIM - d->K + 1 || d->IN_BIT != 8)
+    if (d->IFM_CH % d->SIMD || d->OFM_CH % d->PE || d->OFM_DIM != d->IFM_DIM - d->K + 1 || d->IN_BIT < 1 || d->IN_BIT > 8)
         return SICN_OR_EINVAL;
     const int C = d->IFM_CH, K = d->K, kk = K * K * C, sf_n = kk / d->SIMD, nf_n = d->OFM_CH / d->PE;
     if (d->W_TILES != nf_n * sf_n || d->SIMD * d->W_BIT > 64) return SICN_OR_EINVAL;
@@ -615,7 +615,11 @@ int sicn_or_convlayer_dataflow(const sicn_or_convlayer_desc *d, const uint64_t *
                     for (int s = 0; s < d->SIMD; s++) {
                         int w = (int)((word >> (d->W_BIT * s)) & wmask);
                         if (w >> (d->W_BIT - 1)) w -= 1 << d->W_BIT;
-                        const int x = d->IN_SIGNED ? (int)(int8_t)vec[sf * d->SIMD + s] : (int)vec[sf * d->SIMD + s];
+                        /* one BYTE per lane here (the sliding-window stage moves lanes, not bits); the lane is TSrcI = Slice<ap_(u)int<IN_BIT>>:
+                         * its low IN_BIT bits, sign-extended for ap_int (interpret.hpp:191-244).  The packing of lanes into stream words
+                         * is restated separately (oracle/sicn_ref.py: pack_stream_lanes / unpack_stream_lanes). */
+                        int x = (int)vec[sf * d->SIMD + s] & ((1 << d->IN_BIT) - 1);
+                        if (d->IN_SIGNED && (x >> (d->IN_BIT - 1))) x -= 1 << d->IN_BIT;
                         res = wrap_bits(res + (int64_t)w * x, d->ACC_BIT, d->ACC_SIGNED); /* T res += ...; T = TA */
                     }
                     accu[pe] = res;

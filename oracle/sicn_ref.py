@@ -251,16 +251,44 @@ def _wrap(v: np.ndarray, bits: int, signed: bool) -> np.ndarray:
 
 
 def conv_layer_batch_ref(x: np.ndarray, w_ok: np.ndarray, k: int, in_signed: bool, acc_bit: int, acc_signed: bool,
-                         out_bit: int, thresholds_oi=None, act_val: int = 0) -> np.ndarray:
+                         out_bit: int, thresholds_oi=None, act_val: int = 0, in_bit: int = 8) -> np.ndarray:
     """x [D][D][C] uint8 lanes, w_ok [O][k*k*C] with K index (ky*k+kx)*C + c (slidingwindow.h:163-270 emits
     ky -> kx -> channel).  Stride 1, no padding.  thresholds_oi: [O][NumTH] in channel order, or None for
     PassThroughActivation.  Returns uint32 lanes holding the low out_bit bits."""
     d, _, c = x.shape
     od = d - k + 1
-    xs = x.view(np.int8).astype(np.int64) if in_signed else x.astype(np.int64)
+    xs = _wrap(x, in_bit, in_signed)     # TSrcI = Slice<ap_(u)int<in_bit>>: the lane's low in_bit bits, sign-extended for ap_int
     cols = np.stack([xs[ky:ky + od, kx:kx + od, :] for ky in range(k) for kx in range(k)], axis=2).reshape(od * od, k * k * c)
     acc = _wrap(cols @ w_ok.astype(np.int64).T, acc_bit, acc_signed)
     if thresholds_oi is not None:
         th = _wrap(np.asarray(thresholds_oi), acc_bit, acc_signed)                 # TA m_thresholds
         acc = act_val + (th[None, :, :] < acc[:, :, None]).sum(axis=2)
     return (acc & ((1 << out_bit) - 1)).astype(np.uint32).reshape(od, od, -1)
+
+
+def pack_stream_lanes(lanes: np.ndarray, bits: int) -> np.ndarray:
+    """[...][C] lane values -> the stream words of those pixels as bytes [...][C * bits / 8]: word = sum_c (lane_c mod 2^bits) << (c * bits)
+    (`ap_uint<C * bits>` with Slice<> lane c in bits [c bits, (c + 1) bits), interpret.hpp:191-244; convlayer.h:100), little-endian.
+    Restated with Python integers per pixel, deliberately not with the byte-level shifts the kernels use."""
+    c = lanes.shape[-1]
+    assert (c * bits) % 8 == 0
+    flat = lanes.reshape(-1, c)
+    out = np.empty((flat.shape[0], c * bits // 8), np.uint8)
+    for i, px in enumerate(flat):
+        word = 0
+        for k, v in enumerate(px):
+            word |= (int(v) & ((1 << bits) - 1)) << (k * bits)
+        out[i] = np.frombuffer(word.to_bytes(c * bits // 8, "little"), np.uint8)
+    return out.reshape(lanes.shape[:-1] + (c * bits // 8,))
+
+
+def unpack_stream_lanes(words: np.ndarray, bits: int, channels: int) -> np.ndarray:
+    """Inverse of pack_stream_lanes: bytes [...][C * bits / 8] -> lanes [...][C] as unsigned values (uint32)."""
+    nb = channels * bits // 8
+    assert words.shape[-1] == nb
+    flat = words.reshape(-1, nb)
+    out = np.empty((flat.shape[0], channels), np.uint32)
+    for i, px in enumerate(flat):
+        word = int.from_bytes(px.tobytes(), "little")
+        out[i] = [(word >> (k * bits)) & ((1 << bits) - 1) for k in range(channels)]
+    return out.reshape(words.shape[:-1] + (channels,))

@@ -48,6 +48,7 @@ class ConvLayerDesc:
     W_BIT: int = 4
     IN_SIGNED: bool = False
     OUT_BIT: int = 8
+    IN_BIT: int = 8       # TSrcI::width: 1, 2, 4 or 8 — the input stream carries IFM_CH * IN_BIT bits per pixel (convlayer.h:100)
 
     @property
     def OFM_DIM(self) -> int:
@@ -60,7 +61,7 @@ class ConvLayerDesc:
     def to_c(self, activation) -> "_lib.CConvLayerDesc":
         th = isinstance(activation, ThresholdsActivation)
         return _lib.CConvLayerDesc(K=self.K, IFM_CH=self.IFM_CH, IFM_DIM=self.IFM_DIM, OFM_CH=self.OFM_CH, OFM_DIM=self.OFM_DIM,
-                                   SIMD=self.SIMD, PE=self.PE, IN_BIT=8, IN_SIGNED=int(self.IN_SIGNED), W_BIT=self.W_BIT,
+                                   SIMD=self.SIMD, PE=self.PE, IN_BIT=self.IN_BIT, IN_SIGNED=int(self.IN_SIGNED), W_BIT=self.W_BIT,
                                    W_TILES=self.W_TILES, ACC_BIT=activation.ACC_BIT, ACC_SIGNED=int(activation.ACC_SIGNED),
                                    OUT_BIT=self.OUT_BIT, activation=int(th),
                                    NUM_TH=int(activation.m_thresholds.shape[2]) if th else 0,
@@ -69,8 +70,10 @@ class ConvLayerDesc:
 
 def ConvLayer_Batch(desc: ConvLayerDesc, in_, out, weights: FixedPointWeights, activation, reps: int = 1, stream=None,
                     kernel: int = 0):
-    """in_: CUDA uint8 [reps][IFM_DIM][IFM_DIM][IFM_CH]; out: CUDA tensor [reps][OFM_DIM][OFM_DIM][OFM_CH] of dtype
-    uint8 / int16 / int32 matching OUT_BIT, or None to allocate.  Returns `out`.
+    """in_: CUDA uint8 [reps][IFM_DIM][IFM_DIM][IFM_CH * IN_BIT / 8] — the stream words of the pixels, lane c in bits [c IN_BIT, (c + 1) IN_BIT)
+    (one byte per lane at IN_BIT = 8); out: CUDA tensor [reps][OFM_DIM][OFM_DIM][OFM_CH] of dtype uint8 / int16 / int32 matching OUT_BIT
+    (8 / 16 / 32), or uint8 [reps][OFM_DIM][OFM_DIM][OFM_CH * OUT_BIT / 8] for OUT_BIT 2 / 4 (packed exactly like an input stream, so it
+    can be handed to the next layer as it is), or None to allocate.  Returns `out`.
     kernel: 0 = automatic (MFMA kernel when the shape allows), 1 = the direct kernel (tests compare the two)."""
     import torch
     L = _lib.lib()
@@ -84,9 +87,9 @@ def ConvLayer_Batch(desc: ConvLayerDesc, in_, out, weights: FixedPointWeights, a
         thr = np.ascontiguousarray(activation.m_thresholds, dtype=np.int32)
         if thr.shape[:2] != (desc.PE, desc.OFM_CH // desc.PE):
             raise ValueError("m_thresholds must be [PE][NF][NumTH]")
-    dt = {8: torch.uint8, 16: torch.int16, 32: torch.int32}[desc.OUT_BIT]
-    shape_in = (reps, desc.IFM_DIM, desc.IFM_DIM, desc.IFM_CH)
-    shape_out = (reps, desc.OFM_DIM, desc.OFM_DIM, desc.OFM_CH)
+    dt = {2: torch.uint8, 4: torch.uint8, 8: torch.uint8, 16: torch.int16, 32: torch.int32}[desc.OUT_BIT]
+    shape_in = (reps, desc.IFM_DIM, desc.IFM_DIM, desc.IFM_CH * desc.IN_BIT // 8)
+    shape_out = (reps, desc.OFM_DIM, desc.OFM_DIM, desc.OFM_CH * desc.OUT_BIT // 8 if desc.OUT_BIT < 8 else desc.OFM_CH)
     if not (in_.is_cuda and in_.dtype == torch.uint8 and in_.is_contiguous() and tuple(in_.shape) == shape_in):
         raise TypeError(f"in: need a contiguous CUDA uint8 tensor of shape {shape_in}")
     if out is None:

@@ -40,44 +40,69 @@ __device__ __forceinline__ long long wrap_acc(long long v, int bits, int is_sign
     return (long long)u;
 }
 
+// lane c of a pixel's stream word (interpret.hpp:191-244: Slice<ap_(u)int<W>> reads bits [c W, (c + 1) W)), W in {1, 2, 4, 8}: never
+// straddles a byte
+__device__ __forceinline__ int lane_value(const uint8_t *pixel, int c, int bits, int is_signed)
+{
+    const int off = c * bits;
+    int v = (pixel[off >> 3] >> (off & 7)) & ((1 << bits) - 1);
+    if (is_signed && (v >> (bits - 1))) v -= 1 << bits;
+    return v;
+}
+
+// one thread per output UNIT: a byte holding 8 / OUT_BIT lanes (OUT_BIT < 8) or one lane's container (OUT_BIT >= 8)
 __global__ __launch_bounds__(256) void k_convlayer(const uint8_t *__restrict__ in, void *__restrict__ out,
                                                    const int8_t *__restrict__ w_okc, const int32_t *__restrict__ thr,
                                                    sicn_convlayer_desc d)
 {
-    const size_t per_img = (size_t)d.OFM_DIM * d.OFM_DIM * d.OFM_CH;
+    const int lanes_per_unit = d.OUT_BIT < 8 ? 8 / d.OUT_BIT : 1;
+    const int units_per_pixel = d.OFM_CH / lanes_per_unit;
+    const size_t per_img = (size_t)d.OFM_DIM * d.OFM_DIM * units_per_pixel;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= per_img) return;
     const int img = blockIdx.y;
-    const int o = (int)(idx % d.OFM_CH);
-    const size_t pix = idx / d.OFM_CH;
+    const int unit = (int)(idx % units_per_pixel);
+    const size_t pix = idx / units_per_pixel;
     const int x = (int)(pix % d.OFM_DIM), y = (int)(pix / d.OFM_DIM);
     const int C = d.IFM_CH, K = d.K;
-    const uint8_t *im = in + (size_t)img * d.IFM_DIM * d.IFM_DIM * C;
-    const int8_t *wo = w_okc + (size_t)o * K * K * C;
-    long long acc = 0;   // exact: |sum| <= 121 * C * 255 * 128 fits easily
-    for (int ky = 0; ky < K; ky++)
-        for (int kx = 0; kx < K; kx++) {
-            const uint8_t *s = im + ((size_t)(y + ky) * d.IFM_DIM + (x + kx)) * C;
-            const int8_t *wk = wo + (ky * K + kx) * C;
-            if (d.IN_SIGNED)
-                for (int c = 0; c < C; c++) acc += (int)(int8_t)s[c] * (int)wk[c];
-            else
-                for (int c = 0; c < C; c++) acc += (int)s[c] * (int)wk[c];
+    const int in_pixel_bytes = C * d.IN_BIT / 8;
+    const uint8_t *im = in + (size_t)img * d.IFM_DIM * d.IFM_DIM * in_pixel_bytes;
+    uint32_t packed = 0;
+    for (int l = 0; l < lanes_per_unit; l++) {
+        const int o = unit * lanes_per_unit + l;
+        const int8_t *wo = w_okc + (size_t)o * K * K * C;
+        long long acc = 0;   // exact: |sum| <= 121 * C * 255 * 128 fits easily
+        for (int ky = 0; ky < K; ky++)
+            for (int kx = 0; kx < K; kx++) {
+                const uint8_t *s = im + ((size_t)(y + ky) * d.IFM_DIM + (x + kx)) * in_pixel_bytes;
+                const int8_t *wk = wo + (ky * K + kx) * C;
+                if (d.IN_BIT == 8) {
+                    if (d.IN_SIGNED)
+                        for (int c = 0; c < C; c++) acc += (int)(int8_t)s[c] * (int)wk[c];
+                    else
+                        for (int c = 0; c < C; c++) acc += (int)s[c] * (int)wk[c];
+                } else
+                    for (int c = 0; c < C; c++) acc += lane_value(s, c, d.IN_BIT, d.IN_SIGNED) * (int)wk[c];
+            }
+        const long long a = wrap_acc(acc, d.ACC_BIT, d.ACC_SIGNED);   // TA: every += wraps, the final wrap is the same
+        long long r = a;
+        if (d.activation == SICN_ACT_THRESHOLDS) {
+            r = d.ACT_VAL;
+            const int32_t *t = thr + (size_t)o * d.NUM_TH;
+            for (int i = 0; i < d.NUM_TH; i++) r += (wrap_acc((long long)t[i], d.ACC_BIT, d.ACC_SIGNED) < a) ? 1 : 0;
         }
-    long long a = wrap_acc(acc, d.ACC_BIT, d.ACC_SIGNED);   // TA: every += wraps, the final wrap is the same
-    long long r = a;
-    if (d.activation == SICN_ACT_THRESHOLDS) {
-        r = d.ACT_VAL;
-        const int32_t *t = thr + (size_t)o * d.NUM_TH;
-        for (int i = 0; i < d.NUM_TH; i++) r += (wrap_acc((long long)t[i], d.ACC_BIT, d.ACC_SIGNED) < a) ? 1 : 0;
+        if (d.OUT_BIT < 8)
+            packed |= ((uint32_t)r & ((1u << d.OUT_BIT) - 1)) << (l * d.OUT_BIT);   // lane o in bits [o OUT_BIT, (o + 1) OUT_BIT) of the word
+        else
+            packed = (uint32_t)r;
     }
     const size_t oi = (size_t)img * per_img + idx;
-    if (d.OUT_BIT == 8)
-        ((uint8_t *)out)[oi] = (uint8_t)r;
+    if (d.OUT_BIT <= 8)
+        ((uint8_t *)out)[oi] = (uint8_t)packed;
     else if (d.OUT_BIT == 16)
-        ((uint16_t *)out)[oi] = (uint16_t)r;
+        ((uint16_t *)out)[oi] = (uint16_t)packed;
     else
-        ((uint32_t *)out)[oi] = (uint32_t)r;
+        ((uint32_t *)out)[oi] = packed;
 }
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -181,11 +206,13 @@ extern "C" int sicn_convlayer_validate(const sicn_convlayer_desc *d)
     if (d->K < 1 || d->K > 11 || d->IFM_CH <= 0 || d->OFM_CH <= 0 || d->SIMD <= 0 || d->PE <= 0) return SICN_EINVAL;
     if (d->IFM_DIM < d->K || d->IFM_DIM > (1 << 15) || d->OFM_DIM != d->IFM_DIM - d->K + 1) return SICN_EINVAL;
     if (d->IFM_CH % d->SIMD || d->OFM_CH % d->PE) return SICN_EINVAL;   // slidingwindow.h:177, mvau.hpp:101-105
-    if (d->IN_BIT != 8 || (d->IN_SIGNED != 0 && d->IN_SIGNED != 1)) return SICN_EINVAL;
+    if ((d->IN_BIT != 1 && d->IN_BIT != 2 && d->IN_BIT != 4 && d->IN_BIT != 8) || (d->IN_SIGNED != 0 && d->IN_SIGNED != 1)) return SICN_EINVAL;
+    if ((d->IFM_CH * d->IN_BIT) % 8) return SICN_EINVAL;   // a pixel's stream word is whole bytes
     if (d->W_BIT < 2 || d->W_BIT > 8 || d->SIMD * d->W_BIT > 64) return SICN_EINVAL;
     if ((long long)d->W_TILES != (long long)(d->OFM_CH / d->PE) * ((long long)d->K * d->K * d->IFM_CH / d->SIMD)) return SICN_EINVAL;
     if (d->ACC_BIT < 1 || d->ACC_BIT > 32 || (d->ACC_SIGNED != 0 && d->ACC_SIGNED != 1)) return SICN_EINVAL;
-    if (d->OUT_BIT != 8 && d->OUT_BIT != 16 && d->OUT_BIT != 32) return SICN_EINVAL;
+    if (d->OUT_BIT != 2 && d->OUT_BIT != 4 && d->OUT_BIT != 8 && d->OUT_BIT != 16 && d->OUT_BIT != 32) return SICN_EINVAL;
+    if ((d->OFM_CH * d->OUT_BIT) % 8) return SICN_EINVAL;
     if (d->activation == SICN_ACT_PASSTHROUGH) {
         if (d->NUM_TH != 0) return SICN_EINVAL;
     } else if (d->activation == SICN_ACT_THRESHOLDS) {
@@ -251,7 +278,7 @@ extern "C" int sicn_convlayer_params_create(const sicn_convlayer_desc *d, const 
     p->d_wsum = nullptr;
     bool ok = hipMalloc((void **)&p->d_w_okc, w.size()) == hipSuccess &&
               hipMemcpy(p->d_w_okc, w.data(), w.size(), hipMemcpyHostToDevice) == hipSuccess;
-    if (ok && d->IFM_CH % 16 == 0) {   // the MFMA image: [O/16][tap][C/64][16 rows][64 bytes], zero padded
+    if (ok && d->IFM_CH % 16 == 0 && d->IN_BIT == 8 && d->OUT_BIT >= 8) {   // the MFMA image (byte lanes only): [O/16][tap][C/64][16 rows][64 bytes], zero padded
         const int KK = d->K * d->K, nchunk = (d->IFM_CH + 63) / 64, ntile = (d->OFM_CH + 15) / 16;
         std::vector<int8_t> wm;
         std::vector<int32_t> ws;
@@ -303,10 +330,11 @@ extern "C" int sicn_conv_layer_batch_kernel(const sicn_convlayer_desc *d, const 
         q.activation != d->activation || q.NUM_TH != d->NUM_TH)
         return SICN_EINVAL;
     if (reps == 0) return SICN_OK;
-    const size_t per_img = (size_t)d->OFM_DIM * d->OFM_DIM * d->OFM_CH;
+    if (q.IN_BIT != d->IN_BIT || q.IN_SIGNED != d->IN_SIGNED) return SICN_EINVAL;
+    const size_t per_img = (size_t)d->OFM_DIM * d->OFM_DIM * (d->OUT_BIT < 8 ? d->OFM_CH * d->OUT_BIT / 8 : d->OFM_CH);   // output units
     const size_t blocks = (per_img + 255) / 256;
     if (blocks > 0x7fffffffu) return SICN_EINVAL;
-    if (p->d_w_mfma && (size_t)d->IFM_DIM * d->IFM_DIM * d->IFM_CH < 0x7fffffffu && kernel != SICN_CONVLAYER_KERNEL_DIRECT) {
+    if (p->d_w_mfma && d->IN_BIT == 8 && d->OUT_BIT >= 8 && (size_t)d->IFM_DIM * d->IFM_DIM * d->IFM_CH < 0x7fffffffu && kernel != SICN_CONVLAYER_KERNEL_DIRECT) {
         const unsigned npos = (unsigned)(d->OFM_DIM * d->OFM_DIM);
         dim3 grid((npos + 255) / 256, (unsigned)((d->OFM_CH + 63) / 64), (unsigned)reps);
         hipLaunchKernelGGL(k_convlayer_mfma, grid, dim3(256), 0, (hipStream_t)hip_stream, in, out, p->d_w_mfma, p->d_wsum,

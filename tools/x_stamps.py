@@ -59,9 +59,7 @@ for slot, layer in enumerate((1, 2, 6, 5)):
     s = allr[slot]
     s = s[s[:, 0] > 0]
     if len(s):
-        start, ticks = s[:, 4], s[:, 1]
-        window_us = ((start + ticks).max() - start.min()) / 100.0
-        per[layer] = (ms[layer] / max(cnt[layer], 1), s[:, 2].mean(), (s[:, 0] / s[:, 2]).mean(), window_us, (start.max() - start.min()) / 100.0)
+        per[layer] = (ms[layer] / max(cnt[layer], 1), s[:, 2].mean(), (s[:, 0] / s[:, 2]).mean(), np.median(s[:, 0] / s[:, 1] * 0.1))   # (s_memtime start stamps of different CUs are not comparable: no window)
 for short, long_, name in ((2, 1, "conv"), (5, 6, "deconv")):
     if short in per and long_ in per:
         b, a = fit(per[short][:2], per[long_][:2])
@@ -69,5 +67,6 @@ for short, long_, name in ((2, 1, "conv"), (5, 6, "deconv")):
               f"time = {a * 1e3:.1f} us + {b * 1e3:.2f} us per tile;  the fixed part is {100 * a / per[short][0]:.1f} % of layer {short} and "
               f"{100 * a / per[long_][0]:.1f} % of layer {long_}")
         for l in (long_, short):
-            print(f"   layer {l}: cycles per tile inside the workgroups {per[l][2]:.0f}; all workgroups' window {per[l][3]:.1f} us of the event's {per[l][0] * 1e3:.1f} us "
-                  f"(starts spread over {per[l][4]:.1f} us)")
+            inside = per[l][1] * per[l][2] / per[l][3] / 1e3   # us a workgroup spends on its tiles at the clock it saw
+            print(f"   layer {l}: {per[l][2]:.0f} cycles per tile inside the workgroups at {per[l][3]:.2f} GHz = {inside:.1f} us of the event's {per[l][0] * 1e3:.1f} us "
+                  f"({per[l][0] * 1e3 - inside:.1f} us outside a workgroup's own span: launch, start skew, the slowest workgroup)")
