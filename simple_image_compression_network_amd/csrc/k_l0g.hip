@@ -25,8 +25,11 @@
 
 namespace sicn {
 
-constexpr int L0G_CHUNK = 4;                                   // tiles per run
-constexpr int L0G_RAW_ROWS = 2 * L0_TY * L0G_CHUNK + 3;        // 67
+#ifndef SICN_L0G_CHUNK
+#define SICN_L0G_CHUNK 8
+#endif
+constexpr int L0G_CHUNK = SICN_L0G_CHUNK;                      // tiles per run (8 is the most two workgroups' LDS holds)
+constexpr int L0G_RAW_ROWS = 2 * L0_TY * L0G_CHUNK + 3;        // 131 (round 5: runs of 8 tiles instead of 4: 1.31 -> 1.27 ms on 8 x 4K, profiles/r05_l0g_parts.txt)
 constexpr int L0G_RAW_BYTES = (L0G_RAW_ROWS * L0_RAW_DW + 63) / 64 * 256;   // whole request instructions (64 lanes x 4 B)
 static_assert(L0G_RAW_BYTES >= L0G_RAW_ROWS * L0_RAW_DW * 4 + 12, "the last quad over-reads 3 dwords");
 constexpr int L0G_KSTEPS = 3;                                  // kernel rows (0,1), (2,3), (4, -)
@@ -133,6 +136,7 @@ __global__ __launch_bounds__(512, 2) void k_l0g(const uint8_t *__restrict__ in, 
             acc[0][j] = b4;
             acc[1][j] = b4;
         }
+#ifndef SICN_EXP_L0G_NOL0   // timing experiment (wrong results): the kernel without layer 0's fragment reads and MFMAs
 #pragma unroll
         for (int ks = 0; ks < L0G_KSTEPS; ks++) {
             v4i pf[2];
@@ -149,6 +153,7 @@ __global__ __launch_bounds__(512, 2) void k_l0g(const uint8_t *__restrict__ in, 
                 acc[1][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf, pf[1], acc[1][j], 0, 0, 0);
             }
         }
+#endif
         // the pre-activation lane = the low byte of every accumulator (what k_l0 stores with the RAW floor)
         v4i xf[2][2];
 #pragma unroll
@@ -163,7 +168,12 @@ __global__ __launch_bounds__(512, 2) void k_l0g(const uint8_t *__restrict__ in, 
 #pragma unroll
         for (int it = 0; it < 2; it++) {
             v4i y[2];
+#ifdef SICN_EXP_L0G_NOGDN   // timing experiment (wrong results): the kernel without the activation
+            y[0] = xf[it][0];
+            y[1] = xf[it][1];
+#else
             gdn_item<2, INVERSE>(xf[it], gl, bl, g, pos, kc, y);
+#endif
             const int gx = X0 + 16 * it + pos;
             const bool ok = gy < OH && gx < OW;
 #pragma unroll
