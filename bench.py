@@ -553,9 +553,9 @@ def main():
         # the hand-over) — a service that both encodes and decodes.  The coders are latency-bound chains on a few waves per SIMD; beside a
         # transform kernel of the other job they cost little.  Reported NEXT to the one-stream number, which stays `ms_per_step`.
         two = None
-        try:
-            hc2 = HyperpriorCodec(W, H, B, seed=0, device=dev, main_params=params)
-            pair, outs2 = (hc, hc2), (out_h2, torch.empty_like(out))
+        try:   # built from `guarded` sections and `timed` loops like every leg: a failure surfaces on every rank at the same collective
+            hc2 = guarded(lambda: HyperpriorCodec(W, H, B, seed=0, device=dev, main_params=params))
+            pair, outs2 = (hc, hc2), (out_h2, guarded(lambda: torch.empty_like(out)))
             se, sd = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
             state = {"i": 0, "enc": [None, None], "dec": [None, None]}
 
@@ -575,17 +575,16 @@ def main():
 
             se.wait_stream(torch.cuda.current_stream())
             sd.wait_stream(torch.cuda.current_stream())
-            timed(two_step, 2)
-            tdt = timed(two_step, 2 * (hsteps // 2 + 1))
             nsteps2 = 2 * (hsteps // 2 + 1)
-            hc.check()
-            hc2.check()
+            timed(two_step, 2)
+            tdt = timed(two_step, nsteps2)
+            guarded(lambda: (hc.check(), hc2.check()))
             two = {"ms_per_step": round(tdt / nsteps2 * 1e3, 3), "value": round(world * B * W * H * nsteps2 / tdt / 1e6, 2), "unit": "Mpixels/s",
                    "steps": nsteps2, "outputs_equal_one_stream": bool(torch.equal(outs2[0], direct)) and bool(torch.equal(outs2[1], direct)),
                    "what": "encode(batch k + 1) on one stream beside decode(batch k) on another: two HyperpriorCodec objects, events for the hand-over"}
             del hc2
-        except Exception as e:   # noqa: BLE001   (a secondary of a secondary: never takes the leg down)
-            two = {"error": f"{type(e).__name__}: {e}"}
+        except Exception as e:   # noqa: BLE001   (a secondary of a secondary: reported in its place, never takes the leg down; every rank
+            two = {"error": f"{type(e).__name__}: {e}"}   # arrives here together because the sections above are rank-aligned)
         return {"containers_and_outputs_equal_oracle": oracle_ok, "oracle_checked_images": checked, "two_jobs_in_flight": two,
                 "oracle_check": "sha256 of latent, z container, y container and reconstruction of the timed run vs tests/golden/hyper_4k_hashes.json "
                                 "(oracle/hyper_pipeline.py; GDN specification version 2)",
