@@ -340,6 +340,8 @@ def main():
     # SICN_BENCH_FORCE_DIST=1: create the process group (and run every bookkeeping collective) even for one rank, so that the
     # RCCL code path of the N > 1 runs can be exercised on a 1-GPU box (launch under torch.distributed.run --nproc-per-node 1)
     use_dist = world > 1 or os.environ.get("SICN_BENCH_FORCE_DIST") == "1"
+    if world == 1 and use_dist:   # the one-rank rehearsal: dist.py takes its collective paths (the band split's all-gather) with one rank too
+        os.environ.setdefault("SICN_FORCE_COLLECTIVES", "1")
     if use_dist:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
