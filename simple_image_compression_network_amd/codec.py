@@ -154,7 +154,10 @@ class LatentCoder:
                     device=device if device is not None else slots.device, stream_symbols=int(info.stream_symbols))
         if int(slots.shape[1]) < coder.slot:   # the writer sized its slots for its own stream length; ours can only be equal or smaller
             raise ValueError(f"slots of {int(slots.shape[1])} bytes are shorter than the {coder.slot} bytes a container of this shape may take")
-        coder.slot = int(slots.shape[1])
+        if int(slots.shape[1]) != coder.slot:   # this object's own container buffer follows the slot size it is told to use: an encode()
+            import torch                         # through it must never write past a buffer sized for the smaller slot
+            coder.slot = int(slots.shape[1])
+            coder.slots = torch.empty((coder.shape[0], coder.slot), dtype=torch.uint8, device=coder.slots.device)
         return coder
 
     def encode(self, latents, stream=None):
