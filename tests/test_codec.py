@@ -637,6 +637,10 @@ def test_gpu_decoder_built_from_the_container_header():
     dec.decode(back, slots=slots)
     dec.check()
     assert torch.equal(back, dev)
+    # the adopted object encodes into a buffer of ITS slot size (the writer's), byte-identical to what it was given
+    dec.encode(dev)
+    dec.check()
+    assert dec.sizes() == sizes and all(torch.equal(dec.slots[i, :sizes[i]], slots[i, :sizes[i]]) for i in range(2))
     # and the mismatch the factory exists to prevent: the automatic decoder on the same containers
     auto = codec.LatentCoder(2, *shape)
     assert auto.stream_symbols == 8192
