@@ -825,7 +825,7 @@ hipError_t launch_pipelined(const LayerGeom &g, const sicn_weights &w, const uin
 #define SICN_P(NQ, NT, NTF, D, TX) return launch_p<NQ, NT, NTF, D, TX>(g, w, in, out, n_images, stream, in_layout, out_layout, relu, chip)
 #define SICN_PK(NQ, NT, NTF, D, TX) return launch_p<NQ, NT, NTF, D, TX, NQ / 2>(g, w, in, out, n_images, stream, in_layout, out_layout, relu, chip, ks)
     // The K split (round 4) measured a LOSS on this chip: its instantiations live in the ALT build only (libsicn_alt.so, with
-    // their tests, marked `alt`); the product library rejects sicn_options.split_k > 1 (SICN_EINVAL).
+    // their tests: tests/alt_kernels_check.py); the product library rejects sicn_options.split_k > 1 (SICN_EINVAL).
 #ifndef SICN_ALT_KERNELS
     if (split_k > 1) return hipErrorInvalidValue;
     (void)ks;

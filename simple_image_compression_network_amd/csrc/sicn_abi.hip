@@ -131,7 +131,7 @@ static int resolve_options(const sicn_options *in, sicn_options *out)
         return SICN_EINVAL;
 #ifndef SICN_ALT_KERNELS
     // k_l0p, k_l7s, k_l7g and the K split measured a loss against the defaults: they are built into
-    // libsicn_alt.so only, where their parity tests run (the tests marked `alt`, in a child pytest: tests/conftest.py)
+    // libsicn_alt.so only, where their parity tests run (tests/alt_kernels_check.py)
     if (o.split_k > 1 || o.l7_loader == 2 || o.l0_form == 2 || o.gdn_fuse == 2) return SICN_EINVAL;
 #endif
     *out = o;
