@@ -196,6 +196,32 @@ def gdn(lanes: np.ndarray, beta: np.ndarray, gamma: np.ndarray, inverse: bool, s
     return out
 
 
+def gdn_roots(n: np.ndarray, inverse: bool, shift: int) -> np.ndarray:
+    """oracle/sicn_gdn_oracle.c, the root alone: r (binary32) for every n (uint32, >= 1)."""
+    n = np.ascontiguousarray(n, dtype=np.uint32)
+    r = np.empty(n.shape, np.float32)
+    L = lib()
+    L.sicn_or_gdn_roots.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
+    L.sicn_or_gdn_roots.restype = ctypes.c_int
+    rc = L.sicn_or_gdn_roots(_ptr(n), _ptr(r), n.size, int(bool(inverse)), int(shift))
+    if rc != 0:
+        raise RuntimeError(f"sicn_or_gdn_roots rc={rc}")
+    return r
+
+
+def gdn_outputs(x: np.ndarray, r: np.ndarray) -> np.ndarray:
+    """oracle/sicn_gdn_oracle.c, the output step alone: the stored byte for lanes x (int8) and roots r (binary32)."""
+    x = np.ascontiguousarray(x, dtype=np.int8)
+    r = np.ascontiguousarray(r, dtype=np.float32)
+    assert x.shape == r.shape
+    y = np.empty(x.shape, np.uint8)
+    L = lib()
+    L.sicn_or_gdn_outputs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong]
+    L.sicn_or_gdn_outputs.restype = ctypes.c_int
+    L.sicn_or_gdn_outputs(_ptr(x), _ptr(r), _ptr(y), x.size)
+    return y
+
+
 def run_net(descs, words_list, bias_list, x: np.ndarray, form: str = "dataflow", threads: int = 1):
     outs = []
     for d, w, b in zip(descs, words_list, bias_list):

@@ -66,16 +66,8 @@ static float root_class(int inverse, int SH, unsigned par, unsigned frac)
     return ldexpf((float)M, L - 10 - T + (inverse ? -5 : 5));
 }
 
-/* x: [npos][C] bytes (pre-activation lanes), y: [npos][C] bytes.  gamma: [C][C] row i = output channel. */
-int sicn_or_gdn(const uint8_t *x, uint8_t *y, long long npos, int C, int inverse, int SH, const uint32_t *beta,
-                const uint8_t *gamma)
+static float (*class_table(int inverse, int SH))[1024]
 {
-    if (C <= 0 || C > 1024 || SH < 1 || SH > 24) return -22;
-    for (int i = 0; i < C; i++) {
-        if (beta[i] < 1 || beta[i] > 65535) return -22;
-        for (int j = 0; j < C; j++)
-            if (gamma[(long long)i * C + j] > 127) return -22;
-    }
     static float tab[2][24][2][1024];                      /* [inverse][SH-1][par][frac], filled on demand */
     static unsigned char have[2][24];
     float (*t)[1024] = tab[inverse][SH - 1];
@@ -87,6 +79,61 @@ int sicn_or_gdn(const uint8_t *x, uint8_t *y, long long npos, int C, int inverse
             for (unsigned f = 0; f < 1024; f++) t[par][f] = root_class(inverse, SH, par, f);
         have[inverse][SH - 1] = 1;
     }
+    return t;
+}
+
+/* r for one n: nq from the binary32 conversion of n (IEEE: nearest-even to 24 significant bits) cut to 11 bits, the class's root
+ * scaled by the exponent */
+static float root_of(uint32_t n, int inverse, float (*t)[1024])
+{
+    const float nf = (float)n;
+    uint32_t b;
+    memcpy(&b, &nf, 4);
+    const int E = (int)(b >> 23) - 127;                    /* nq = 2^E (1 + frac / 1024) */
+    const unsigned par = (unsigned)E & 1u, frac = (b >> 13) & 1023u;
+    const int j2 = (E - (int)par) / 2;                     /* nq = 4^j2 * class value: the root scales by 2^-j2 / 2^+j2 */
+    return ldexpf(t[par][frac], inverse ? j2 : -j2);
+}
+
+static uint8_t output_of(int x, float r)
+{
+    const float u = fmaf((float)x, r, 128.0f);
+    float q = nearbyintf(u);                               /* default rounding mode: nearest-even */
+    if (!(q > 0.0f)) q = 0.0f;
+    if (q > 255.0f) q = 255.0f;
+    return (uint8_t)((unsigned)q ^ 0x80u);
+}
+
+/* Test hooks: the two halves of the per-element arithmetic on their own, so that tests/test_gdn.py can hold this statement and the
+ * integer-only one of oracle/sicn_ref.py together EXHAUSTIVELY (every class of nq at every exponent and shift; every r x every lane). */
+int sicn_or_gdn_roots(const uint32_t *n, float *r, long long count, int inverse, int SH)
+{
+    if (SH < 1 || SH > 24 || (inverse != 0 && inverse != 1)) return -22;
+    float (*t)[1024] = class_table(inverse, SH);
+    for (long long i = 0; i < count; i++) {
+        if (n[i] == 0) return -22;
+        r[i] = root_of(n[i], inverse, t);
+    }
+    return 0;
+}
+
+int sicn_or_gdn_outputs(const int8_t *x, const float *r, uint8_t *y, long long count)
+{
+    for (long long i = 0; i < count; i++) y[i] = output_of((int)x[i], r[i]);
+    return 0;
+}
+
+/* x: [npos][C] bytes (pre-activation lanes), y: [npos][C] bytes.  gamma: [C][C] row i = output channel. */
+int sicn_or_gdn(const uint8_t *x, uint8_t *y, long long npos, int C, int inverse, int SH, const uint32_t *beta,
+                const uint8_t *gamma)
+{
+    if (C <= 0 || C > 1024 || SH < 1 || SH > 24) return -22;
+    for (int i = 0; i < C; i++) {
+        if (beta[i] < 1 || beta[i] > 65535) return -22;
+        for (int j = 0; j < C; j++)
+            if (gamma[(long long)i * C + j] > 127) return -22;
+    }
+    float (*t)[1024] = class_table(inverse, SH);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static)
 #endif
@@ -101,18 +148,7 @@ int sicn_or_gdn(const uint8_t *x, uint8_t *y, long long npos, int C, int inverse
         for (int i = 0; i < C; i++) {
             uint32_t n = beta[i];
             for (int j = 0; j < C; j++) n += (uint32_t)gamma[(long long)i * C + j] * sq[j];
-            const float nf = (float)n;                      /* IEEE: nearest-even to 24 significant bits */
-            uint32_t b;
-            memcpy(&b, &nf, 4);
-            const int E = (int)(b >> 23) - 127;             /* nq = 2^E (1 + frac / 1024) */
-            const unsigned par = (unsigned)E & 1u, frac = (b >> 13) & 1023u;
-            const int j2 = (E - (int)par) / 2;              /* nq = 4^j2 * class value: the root scales by 2^-j2 / 2^+j2 */
-            const float r = ldexpf(t[par][frac], inverse ? j2 : -j2);
-            const float u = fmaf((float)xs[i], r, 128.0f);
-            float q = nearbyintf(u);                        /* default rounding mode: nearest-even */
-            if (!(q > 0.0f)) q = 0.0f;
-            if (q > 255.0f) q = 255.0f;
-            y[p * C + i] = (uint8_t)((unsigned)q ^ 0x80u);
+            y[p * C + i] = output_of(xs[i], root_of(n, inverse, t));
         }
     }
     return 0;

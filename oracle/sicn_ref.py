@@ -188,8 +188,15 @@ def gdn_ref(lanes: np.ndarray, beta: np.ndarray, gamma: np.ndarray, inverse: boo
     roots = [gdn_root(*gdn_quantise_n(int(v)), inverse, shift) for v in uniq]
     big_m = np.array([r[0] for r in roots], np.int64)[inv].reshape(n.shape)
     k = np.array([r[1] for r in roots], np.int64)[inv].reshape(n.shape)
+    return gdn_output_ref(x, big_m, k).reshape(lanes.shape)
+
+
+def gdn_output_ref(x: np.ndarray, big_m: np.ndarray, k: np.ndarray) -> np.ndarray:
+    """The output step in integers: the stored byte for lanes x (int64, -128 .. 127) and roots r = big_m 2^k (1024 <= big_m < 2048):
+    u = x r + 128 rounded once to 24 significant bits (nearest-even), then to the nearest-even integer, clamped to 0 .. 255, minus 128."""
+    x, big_m, k = np.broadcast_arrays(np.asarray(x, np.int64), np.asarray(big_m, np.int64), np.asarray(k, np.int64))
     p = x * big_m                                            # |p| < 2^19; the exact value is p 2^k + 128
-    out = np.empty(n.shape, np.int64)
+    out = np.empty(p.shape, np.int64)
     pos = k >= 0                                             # an integer: below 2^24 it is exact, above it the clamp decides
     out[pos] = np.clip((p[pos] << k[pos]) + 128, 0, 255)
     s = -k[~pos]
@@ -203,7 +210,7 @@ def gdn_ref(lanes: np.ndarray, beta: np.ndarray, gamma: np.ndarray, inverse: boo
     q, rem, half = v >> s, v & ((np.int64(1) << s) - 1), np.int64(1) << (s - 1)   # second rounding: to an integer (s >= 1)
     y = q + ((rem > half) | ((rem == half) & (q & 1 == 1)))
     out[~pos] = np.where(neg, 0, np.clip(y, 0, 255))
-    return ((out - 128) & 0xFF).astype(np.uint8).reshape(lanes.shape)
+    return ((out - 128) & 0xFF).astype(np.uint8)
 
 
 Params = Sequence[Tuple[np.ndarray, np.ndarray, int]]   # (W[o][ky][kx][c], bias[o], transposed)

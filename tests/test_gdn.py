@@ -80,6 +80,58 @@ def test_rounding_bias_keeps_every_class_away_from_a_step(inverse):
     assert worst >= 7.5, worst
 
 
+def _roots_as_m_k(r: np.ndarray):
+    """binary32 roots -> (M, k) with r = M 2^k, 1024 <= M < 2048 (exact: r has 11 significant bits)."""
+    b = np.ascontiguousarray(r, np.float32).view(np.uint32).astype(np.int64)
+    assert np.all((b & 0x1FFF) == 0) and np.all(b >> 31 == 0)
+    return ((b & 0x7FFFFF) | 0x800000) >> 13, (b >> 23) - 127 - 10
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_two_oracle_statements_agree_on_every_root(inverse):
+    """EXHAUSTIVE over what r can depend on: every class of nq (2 parities x 1024 fractions) at every exponent a
+    u32 n can have, at the class's first and last n and their neighbours (where the 24-bit rounding of n >= 2^24 and the cut to 11 bits
+    decide), for every shift 1 .. 24 — the C statement (binary32 conversion, 128-bit bisection over the classes, ldexp) against the
+    Python one (integer rounding, math.isqrt on big integers)."""
+    ns = set()
+    for e in range(0, 31):                                           # n in [2^e, 2^(e+1))
+        lo = 1 << e
+        width = max(lo >> 10, 1)                                     # n's per class (>= 1)
+        for f in range(0, 1024) if e >= 10 else range(0, lo):
+            first = lo + f * width
+            for n in (first - 1, first, first + 1, first + width // 2 - 1, first + width // 2, first + width - 1):
+                if 1 <= n < (1 << 31):
+                    ns.add(n)
+    ns = np.array(sorted(ns), np.uint32)
+    assert ns.size > 100000
+    quant = [sicn_ref.gdn_quantise_n(int(n)) for n in ns]
+    for shift in range(1, 25):
+        r = c_oracle.gdn_roots(ns, inverse, shift)
+        big_m, k = _roots_as_m_k(r)
+        # the mantissa of r does not depend on the shift (trunc11 is scale-invariant): the full comparison at every shift for a stride
+        # of the n's, and for ALL of them at three shifts
+        step = 1 if shift in (1, 12, 24) else 41
+        for i in range(0, ns.size, step):
+            assert (int(big_m[i]), int(k[i])) == sicn_ref.gdn_root(*quant[i], inverse, shift), (int(ns[i]), shift)
+        if shift > 1:      # ... and the scale-invariance itself, for every n: one more shift = one less in the exponent, the same mantissa
+            assert np.array_equal(big_m, prev_m) and np.array_equal(k, prev_k - 1), shift
+        prev_m, prev_k = big_m, k
+
+
+def test_two_oracle_statements_agree_on_every_output():
+    """EXHAUSTIVE over the output step: every 11-bit root mantissa (1024) x every exponent the roots can have (k = -34 .. 13: both
+    activations, all shifts, all n) x every lane value (256) — 12.6 M combinations: fmaf + nearbyintf + clamp in C against the two
+    integer roundings in Python."""
+    m = np.arange(1024, 2048, dtype=np.int64)
+    x = np.arange(-128, 128, dtype=np.int64)
+    for k in range(-34, 14):
+        r = np.ldexp(m.astype(np.float64), k).astype(np.float32)                 # exact: 11 significant bits
+        rr, xx = np.meshgrid(r, x.astype(np.int8), indexing="ij")
+        got = c_oracle.gdn_outputs(xx, rr)
+        want = sicn_ref.gdn_output_ref(x[None, :], m[:, None], np.int64(k))
+        assert np.array_equal(got, want), k
+
+
 def test_specification_properties():
     rng = np.random.default_rng(5)
     c = 16
