@@ -70,3 +70,19 @@ for short, long_, name in ((2, 1, "conv"), (5, 6, "deconv")):
             inside = per[l][1] * per[l][2] / per[l][3] / 1e3   # us a workgroup spends on its tiles at the clock it saw
             print(f"   layer {l}: {per[l][2]:.0f} cycles per tile inside the workgroups at {per[l][3]:.2f} GHz = {inside:.1f} us of the event's {per[l][0] * 1e3:.1f} us "
                   f"({per[l][0] * 1e3 - inside:.1f} us outside a workgroup's own span: launch, start skew, the slowest workgroup)")
+
+# ---- per-XCD balance of the static tile deal: does one XCD finish later than the others? (spans in cycles and in 100 MHz ticks = real time) ----
+for slot, layer in enumerate((1, 2, 6, 5)):
+    s = allr[slot]
+    s = s[s[:, 0] > 0]
+    if not len(s):
+        continue
+    xs = np.unique(s[:, 6])
+    rows = []
+    for xcc in xs:
+        t = s[s[:, 6] == xcc]
+        rows.append((int(xcc) & 15, len(t), t[:, 2].mean(), t[:, 1].mean() / 100.0, t[:, 1].max() / 100.0, np.median(t[:, 0] / t[:, 1] * 0.1)))
+    worst = max(r[4] for r in rows)
+    print(f"layer {layer}: per XCD (id: workgroups, tiles each, mean span us, max span us, GHz): " +
+          "; ".join(f"{r[0]}: {r[1]}, {r[2]:.1f}, {r[3]:.0f}, {r[4]:.0f}, {r[5]:.2f}" for r in rows) +
+          f"  | all: mean {s[:, 1].mean() / 100.0:.0f} us, max {worst:.0f} us ({100 * (worst / (s[:, 1].mean() / 100.0) - 1):.1f} % above the mean)")
