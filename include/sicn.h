@@ -137,7 +137,8 @@ const char *sicn_strerror(int code);
  * 64 -> 2, CPX 32 -> 1; hipDeviceProp_t carries no XCD count, and the value only steers which tiles share an L2).
  * sicn_debug_plan shows what a layer would launch on a chip of n_cu CUs, without a GPU: out[] = { n_cu, n_xcd, kernel kind
  * (0 generic, 1 mfma conv, 2 mfma deconv, 3 layer 0, 4 layer 7), mfma family (0 plain, 1 pipelined, 2 wide persistent), tile_x,
- * split_n, split_k, grid x, grid y, grid z, strip chunks, layer-0 tiles per run }.  sicn_debug_xcd_item is the host mirror of
+ * split_n, split_k, grid x, grid y, grid z, strip chunks (wide persistent: 1 = part of the tiles dealt dynamically), layer-0 tiles per
+ * run }.  sicn_debug_xcd_item is the host mirror of
  * the kernels' workgroup -> work item mapping (-1: padding workgroup). */
 /* dst[n][h][w][c] = the top-left h x w corner of every image of src[n][src_h][src_w][c] (device pointers, one launch, enqueue
  * only).  A deconv522 doubles a size that a conv2d rounded up, so a tensor rebuilt by deconvs can be one row / column larger than
@@ -158,8 +159,8 @@ void sicn_options_init(sicn_options *opt);
  * `word_bytes` (1,2,4 or 8) little-endian bytes; `bias` = HOST int8[OFM_CH].  Only desc fields
  * IFM_CH, OFM_CH, SIMD, PE, W_TILES, transposed are used (weights do not depend on image size).
  * Synchronous (uploads to the current device).  A handle is immutable after creation: any number of launches, streams,
- * host threads and captured graphs may use it at the same time (the persistent kernels deal their tiles statically and
- * keep no scheduler state). */
+ * host threads and captured graphs may use it at the same time (the persistent kernels keep no scheduler state in a handle:
+ * tiles are dealt statically, and the dynamic part of the wide kernels' deal lives in the workspace of the call, below). */
 int sicn_weights_from_finn_tiles(const sicn_layer_desc *desc, const void *m_weights, int word_bytes,
                                  const int8_t *bias, sicn_weights **out);
 void sicn_weights_free(sicn_weights *w);
@@ -193,7 +194,11 @@ void sicn_net_free(sicn_net *net);
  * whose grids are small enough for the K split (sicn_options.split_k), the slices' partial output tensors and one arrival word
  * per workgroup.  The scratch needs NO initialisation: an arrival word only counts when it carries the net's random 56-bit tag,
  * and the workgroup that finishes a tile clears it (any other content, e.g. uninitialised memory, reads as "nobody arrived").
- * Depends on the current device's CU count (K split is a small-grid measure); asked without a device it assumes 256 CUs. */
+ * Depends on the current device's CU count (K split is a small-grid measure); asked without a device it assumes 256 CUs.
+ * Behind those: 528 words per layer for the wide persistent kernels' tile deal (one ticket counter per XCD + one mailbox per
+ * workgroup, k_mfma16x.hip DealX), which sicn_net_forward zeroes itself (one small kernel at the head of the call).  A workspace
+ * without room for them (a size computed by library 0.2) still works: those kernels then deal all their tiles statically.
+ * Like the ping-pong buffers, a workspace serves ONE call in flight at a time. */
 size_t sicn_net_workspace_bytes(const sicn_net *net, int n_images);
 /* Runs layers [first_layer, last_layer] of the chain.  `tap_layer` >= 0 additionally delivers that
  * layer's output (e.g. 3 = the latent, conv_3_out, conv_nonsquare_top.cpp:322-325) in `tap_out` (NHWC): an inner

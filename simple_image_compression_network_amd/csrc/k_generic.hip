@@ -60,6 +60,19 @@ hipError_t launch_generic(const LayerGeom &g, const sicn_weights &w, const uint8
 // ---- crop of a batch of NHWC tensors: dst[n][h][w][c] = src[n][y < h][x < w][c] of [n][hs][ws][c], ONE launch ------------------
 // (a deconv522 doubles a size that a conv2d rounded up, so a decoded map can be one row / column larger than the tensor it models:
 // the hyperprior's scale map.  torch's strided copy_ did this as one D2D memcpy per image: 16 launches of ~50 us per 8 x 4K step.)
+// zero `words` 64-bit words (the tile-deal area of a forward pass: a kernel node rather than a memset node, see sicn_net_forward)
+__global__ __launch_bounds__(256) void k_zero_words(unsigned long long *p, int words)
+{
+    for (int i = (int)(blockIdx.x * 256 + threadIdx.x); i < words; i += (int)gridDim.x * 256) p[i] = 0ull;
+}
+hipError_t launch_zero_words(unsigned long long *p, size_t words, hipStream_t stream)
+{
+    if (!words) return hipSuccess;
+    const unsigned blocks = (unsigned)((words + 255) / 256 < 64 ? (words + 255) / 256 : 64);
+    hipLaunchKernelGGL(k_zero_words, dim3(blocks), dim3(256), 0, stream, p, (int)words);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void k_crop_nhwc(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int n, int hs, int ws,
                                                    int h, int w, int c, int vec)
 {

@@ -411,6 +411,7 @@ MfmaPlan plan_mfma(const LayerGeom &g, int n_images, const sicn_options &o, cons
         if (o.wave_tile == 128 || (o.wave_tile == 0 && o.prefetch == 0 && wide_automatic(tiles_w, deconv, chip))) {
             p.family = 2;
             p.grid_x = wide_grid(tiles_w, o.persistent_grid, chip);
+            p.deal = wide_deal_pays(tiles_w, p.grid_x, chip);
             return p;
         }
     }
@@ -447,7 +448,7 @@ static hipError_t launch16(const LayerGeom &g, const sicn_weights &w, const uint
                            const KSplitScratch *ks)
 {
     MfmaPlan p = plan_mfma(g, n_images, o, chip);
-    if (p.family == 2) return launch_wide(g, w, in, out, n_images, stream, in_layout, out_layout, relu, o.persistent_grid, chip);
+    if (p.family == 2) return launch_wide(g, w, in, out, n_images, stream, in_layout, out_layout, relu, o.persistent_grid, chip, ks ? ks->deal : nullptr);
     if (p.family == 1) {
         // (round 2 sent the deconv 192 -> 128 on full grids back to the plain kernel: the pipelined one was 7 % slower there.  The
         // reason was the v_mov copies hipcc made for its run-time buffer parity — right around the asm MFMAs, where

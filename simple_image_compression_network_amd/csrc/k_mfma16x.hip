@@ -260,6 +260,126 @@ __device__ __forceinline__ void set_out_off_x(uint32_t (&off)[8], const TensorMa
     }
 }
 
+// ---- the tile deal across the XCDs (round 5) --------------------------------------------------------------------------------
+// The eight XCDs do not hold the same clock under this load (in-kernel stamps: 1.92 - 2.08 GHz, the same XCDs slow in every layer of a
+// pass), so with the same number of tiles per XCD the kernel ends 3.3 - 4.5 % after its average workgroup.  With a `deal` area (words of
+// the net's workspace, zeroed once per forward pass) a workgroup walks TWO tiles of the static deal and takes every further one from a
+// ticket counter: its own XCD's (the contiguous range of §3.1 stays contiguous) and, once that is used up, the other XCDs' in turn.
+//   words [0, 16): ticket counters, one per XCD (low 32 bits);  word 16 + blockIdx.x: the workgroup's mailbox = (sequence << 32) | (item + 1)
+// Wave 0 takes the ticket for the workgroup's tile j + 2 while tile j runs (one lane, an asm atomic nobody waits for: its result is read
+// six passes later, and checked), resolves it and publishes it in the mailbox; ALL four waves read the mailbox with a scalar load early in
+// tile j + 1 — complete at that pass's barrier (lgkmcnt(0)), no LDS word needed (k_deconv_x has none to give) — and spin only if the
+// sequence number is not there yet.  deal == nullptr (a single layer outside a net): the static deal, as before.
+struct DealX {
+    unsigned long long ws;   // the deal area's address, or 0: the static deal.  Kept in a VGPR pair (the kernels have no SGPR to spare)
+    int xcd, n_xcd, per, stride, total;
+};
+constexpr int DEAL_MAILBOX0 = 16;
+constexpr uint32_t DEAL_PENDING = 0xFFFFFFFFu;
+
+// item of ticket t of XCD y, or -1: tickets count the tiles BEHIND the two static rounds of y's range
+__device__ __forceinline__ int deal_item(const DealX &d, int y, uint32_t t)
+{
+    const long idx = (long)y * d.per + 2L * d.stride + (long)t;
+    const long end = min((long)d.total, (long)(y + 1) * d.per);
+    return (t < 0x7fffffffu && idx < end) ? (int)idx : -1;
+}
+// wave 0: one lane takes a ticket from XCD y's counter; the value arrives in tk some time later (DEAL_PENDING until then)
+__device__ __forceinline__ void deal_ticket_issue(const DealX &d, int y, uint32_t &tk, int lane)
+{
+    tk = DEAL_PENDING;
+    asm volatile("" : "+v"(tk));
+    if (lane == 0) {
+        const unsigned long long p = d.ws + (unsigned long long)y * 8u;
+        const uint32_t one = 1u;
+        asm volatile("global_atomic_add %0, %1, %2, off sc0" : "+v"(tk) : "v"(p), "v"(one) : "memory");
+    }
+}
+__device__ __forceinline__ uint32_t deal_ticket_value(uint32_t &tk)   // wave 0; blocks only if the atomic has not come back
+{
+    asm volatile("" : "+v"(tk));
+    uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+    if (t == DEAL_PENDING) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(tk));
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+    }
+    return t;
+}
+// wave 0: the ticket (of the own XCD) -> an item.  Own range used up: ONE look at all counters (lane y reads XCD y's), then a ticket from
+// the XCD with the most tiles left — two round trips (~ 3 us, once in a workgroup's life) instead of up to seven blind ones (measured:
+// + 10 us on every launch); a lost race looks again.
+__device__ __forceinline__ int deal_resolve(const DealX &d, uint32_t &tk, int lane)
+{
+    uint32_t t = deal_ticket_value(tk);
+    int it = deal_item(d, d.xcd, t);
+    if (it >= 0) return it;
+#pragma unroll 1
+    for (int attempt = 0; attempt < 4; attempt++) {
+        uint32_t c = 0x7fffffffu;
+        asm volatile("" : "+v"(c));
+        if (lane < d.n_xcd) {
+            const unsigned long long p = d.ws + (unsigned long long)lane * 8u;
+            asm volatile("global_load_dword %0, %1, off sc0 sc1" : "+v"(c) : "v"(p) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(c));
+        int best = -1;
+        long best_left = 0;
+#pragma unroll 1
+        for (int y = 0; y < d.n_xcd; y++) {
+            const long taken = (long)(uint32_t)__builtin_amdgcn_readlane((int)c, y);
+            const long left = min((long)d.total, (long)(y + 1) * d.per) - (long)y * d.per - 2L * d.stride - taken;
+            if (left > best_left) {
+                best_left = left;
+                best = y;
+            }
+        }
+        if (best < 0) return -1;
+        deal_ticket_issue(d, best, tk, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        it = deal_item(d, best, deal_ticket_value(tk));
+        if (it >= 0) return it;
+    }
+    return -1;
+}
+__device__ __forceinline__ void deal_publish(const DealX &d, uint32_t seq, int item, int lane)   // wave 0
+{
+    if (lane == 0) {
+        const unsigned long long p = d.ws + (unsigned long long)(DEAL_MAILBOX0 + (int)blockIdx.x) * 8u;
+        const unsigned long long v = ((unsigned long long)seq << 32) | (unsigned long long)(uint32_t)(item + 1);
+        asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    }
+}
+// all waves: request the mailbox (every lane the same 8 bytes; nobody waits: the passes' counted waits retire it) ...
+__device__ __forceinline__ void deal_request(const DealX &d, unsigned long long &m)
+{
+    const unsigned long long p = d.ws + (unsigned long long)(DEAL_MAILBOX0 + (int)blockIdx.x) * 8u;
+    m = 0;
+    asm volatile("" : "+v"(m));
+    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "+v"(m) : "v"(p) : "memory");
+}
+// ... and take it: the item published under sequence number `seq`, -1 = none.  Re-reads (blocking, bounded: a bug must not hang the
+// chip) only if the load has not landed or wave 0 has not published yet.
+__device__ __forceinline__ int deal_take(const DealX &d, unsigned long long &m, uint32_t seq)
+{
+    asm volatile("" : "+v"(m));
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32));
+    if (hi != seq) {
+#pragma unroll 1
+        for (int spin = 0; spin < (1 << 16) && hi != seq; spin++) {
+            deal_request(d, m);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(m));
+            lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+            hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32));
+            if (hi != seq) __builtin_amdgcn_s_sleep(8);
+        }
+        if (hi != seq) return -1;
+    }
+    return (int)lo - 1;
+}
+
 // =====================================================================================================================
 // conv2d<>
 // =====================================================================================================================
@@ -451,7 +571,8 @@ constexpr int SWITCH_T = 25 + 16;                 // from this pass of a tile on
 template <bool NT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_conv_x(
     const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int8_t *__restrict__ wstream, const int8_t *__restrict__ bias_g, int IW,
-    int IH, int OW, int OH, int tiles_x, int n_tiles, int n_images, int in_layout, int out_layout, uint32_t act_floor, int n_xcd)
+    int IH, int OW, int OH, int tiles_x, int n_tiles, int n_images, int in_layout, int out_layout, uint32_t act_floor, int n_xcd,
+    unsigned long long *deal)
 {
     constexpr int CIN = 128, COUT = 128;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -468,6 +589,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int item = xcd * per + (int)blockIdx.x / n_xcd;
     const int item_end = min(total, (xcd + 1) * per);
     if (item >= item_end) return;   // before any barrier or request
+    const DealX dl{(unsigned long long)(uintptr_t)deal, xcd, n_xcd, per, stride, total};
     stagger_x(n_xcd);
     auto coord = [&](int it) {
         const int img = it / n_tiles, tile = it - img * n_tiles, ty = tile / tiles_x;
@@ -541,6 +663,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int st_tiles = 1;
 #endif
     bool stores = false;   // a hand-over's stores may be in flight (not in the first tile)
+    int tile_no = 0;         // tiles this workgroup has finished (DealX: the mailbox's sequence numbers)
+    uint32_t deal_tk = DEAL_PENDING;
+    unsigned long long deal_mail = 0;
+    bool deal_done = false;  // wave 0: "none" has been published
 #pragma unroll 1
     for (;;) {
         {   // keep hipcc from hoisting the tile's ~180 LDS-DMA destinations (M0 values) out of the tile loop: it did, and spilled
@@ -550,10 +676,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             ctx.planes_w = pw;
             ctx.ring_w = rw_;
         }
-        conv_passes_x<1, SWITCH_T, NT>(acc, pa, wa, pb, wb, ctx, poff, stores, h, bias);
+        // the next tile: tile 1 is the static deal's; from then on it was published in the mailbox while the previous tile ran (DealX)
+        int next = item + stride;
+        const bool dyn = dl.ws != 0, later = dyn && tile_no > 0;
+        conv_passes_x<1, 3, NT>(acc, pa, wa, pb, wb, ctx, poff, stores, h, bias);
+        if (later) deal_request(dl, deal_mail);
+        conv_passes_x<3, 7, NT>(acc, pa, wa, pb, wb, ctx, poff, stores, h, bias);
+        if (later) next = deal_take(dl, deal_mail, (uint32_t)tile_no + 1u);
+        // a ticket is only taken for a tile this workgroup will get to: the one behind `next`
+        const bool has_next = dyn ? (next >= 0 && (tile_no > 0 || next < item_end)) : next < item_end;
+        const bool goes_on = dyn && has_next && w == 0 && !deal_done;
+        if (goes_on) deal_ticket_issue(dl, dl.xcd, deal_tk, lane);
+        conv_passes_x<7, 13, NT>(acc, pa, wa, pb, wb, ctx, poff, stores, h, bias);
+        if (goes_on) {
+            const int it2 = deal_resolve(dl, deal_tk, lane);
+            deal_publish(dl, (uint32_t)tile_no + 2u, it2, lane);
+            deal_done = it2 < 0;
+        }
+        conv_passes_x<13, SWITCH_T, NT>(acc, pa, wa, pb, wb, ctx, poff, stores, h, bias);
         // every plane request for THIS tile has been issued: the rest of the tile fetches the next tile's first group
-        const int next = item + stride;
-        const bool has_next = next < item_end;
         const TileX tn = coord(has_next ? next : item);
         int lane_l;   // recomputed, not kept
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_l));
@@ -577,6 +718,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (!has_next) break;
         item = next;
         tc = tn;
+        tile_no++;
 #ifdef SICN_STAMP
         st_tiles++;
 #endif
@@ -742,7 +884,8 @@ __device__ __forceinline__ void deconv_pass_x(v4i (&acc)[8][8], const v4i (&pc)[
 template <bool NT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_deconv_x(
     const uint8_t *__restrict__ in, uint8_t *__restrict__ out, const int8_t *__restrict__ wstream, const int8_t *__restrict__ bias_g, int IW,
-    int IH, int OW, int OH, int tiles_x, int n_tiles, int n_images, int in_layout, int out_layout, uint32_t act_floor, int n_xcd)
+    int IH, int OW, int OH, int tiles_x, int n_tiles, int n_images, int in_layout, int out_layout, uint32_t act_floor, int n_xcd,
+    unsigned long long *deal)
 {
     constexpr int CIN = 128, COUT = 128;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -757,6 +900,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int item = xcd * per + (int)blockIdx.x / n_xcd;
     const int item_end = min(total, (xcd + 1) * per);
     if (item >= item_end) return;
+    const DealX dl{(unsigned long long)(uintptr_t)deal, xcd, n_xcd, per, stride, total};
     stagger_x(n_xcd);
     auto coord = [&](int it) {
         const int img = it / n_tiles, tile = it - img * n_tiles, ty = tile / tiles_x;
@@ -839,6 +983,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int st_tiles = 1;
 #endif
     bool stores = false;   // a hand-over's stores may be in flight (in the first tile: from its phase 1 on)
+    int tile_no = 0;         // tiles this workgroup has finished (DealX: the mailbox's sequence numbers)
+    uint32_t deal_tk = DEAL_PENDING;
+    unsigned long long deal_mail = 0;
+    bool deal_done = false;  // wave 0: "none" has been published
 #pragma unroll 1
     for (;;) {
         {
@@ -855,14 +1003,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         deconv_pass_x<T, dphase_start(T) ? 2 : 0, NT>(acc, pb, wb, pa, wa, ctx, poff_cur, poff_next, ST, h, bias);
         // `stores`: passes 1 .. 7 store the previous tile's last phase (none in the first tile), and a wait counts the stores of
         // the passes up to FLIGHT - 1 back
-        SICN_DP(1, stores) SICN_DP(2, stores) SICN_DP(3, stores) SICN_DP(4, stores) SICN_DP(5, stores)
+        // the next tile (its patch is requested from pass 6 on): tile 1 is the static deal's, from then on it comes from the mailbox,
+        // where wave 0 published it while the previous tile ran (DealX)
+        const bool dyn = dl.ws != 0, later = dyn && tile_no > 0;
+        SICN_DP(1, stores)
+        if (later) deal_request(dl, deal_mail);
+        SICN_DP(2, stores) SICN_DP(3, stores) SICN_DP(4, stores) SICN_DP(5, stores)
+        if (later) {
+            next = deal_take(dl, deal_mail, (uint32_t)tile_no + 1u);
+            has_next = next >= 0;
+            tn = coord(has_next ? next : item);
+        }
+        const bool goes_on = dyn && has_next && w == 0 && !deal_done;   // a ticket is only taken for a tile this workgroup will get to
         {
             int lane_l;
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_l));
             set_dpoff_x(poff_next, im, tn, w, lane_l, IW, IH, has_next);
             ctx.next_img = in + (size_t)tn.img * in_img_bytes;
         }
-        SICN_DP(6, stores) SICN_DP(7, stores) SICN_DP(8, stores) SICN_DP(9, stores)
+        SICN_DP(6, stores) SICN_DP(7, stores)
+        if (goes_on) deal_ticket_issue(dl, dl.xcd, deal_tk, lane);
+        SICN_DP(8, stores) SICN_DP(9, stores)
         {   // the previous tile's last stores are out: from here on the hand-overs are this tile's phases
             int lane_l;
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_l));
@@ -870,7 +1031,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             set_out_off_x(h.off, om, tc, w, lane_l, IW, IH, 2);
         }
         SICN_DP(10, true) SICN_DP(11, true) SICN_DP(12, true) SICN_DP(13, true)
-        SICN_DP(14, true) SICN_DP(15, true) SICN_DP(16, true) SICN_DP(17, true)
+        SICN_DP(14, true)
+        if (goes_on) {
+            const int it2 = deal_resolve(dl, deal_tk, lane);
+            deal_publish(dl, (uint32_t)tile_no + 2u, it2, lane);
+            deal_done = it2 < 0;
+        }
+        SICN_DP(15, true) SICN_DP(16, true) SICN_DP(17, true)
         h.soff = phase_soff(0);
         asm volatile("s_nop 7" ::: "memory");   // the last MFMAs' results -> v_accvgpr_read
         SICN_DP(18, true) SICN_DP(19, true) SICN_DP(20, true) SICN_DP(21, true) SICN_DP(22, true) SICN_DP(23, true) SICN_DP(24, true) SICN_DP(25, true)
@@ -907,9 +1074,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (!has_next) break;
         item = next;
         tc = tn;
-        next = item + stride;
-        has_next = next < item_end;
-        tn = coord(has_next ? next : item);
+        tile_no++;
+        if (!dl.ws) {   // the static deal; with a deal area the next tile is read from the mailbox at the top of the loop
+            next = item + stride;
+            has_next = next < item_end;
+            tn = coord(has_next ? next : item);
+        }
 #ifdef SICN_STAMP
         st_tiles++;
 #endif
@@ -959,7 +1129,7 @@ void pack_mfma16x_deconv_stream(const int8_t *w_okc, int cin, int cout, int8_t *
 bool wide_supported(const LayerGeom &g) { return g.CIN == 128 && g.COUT == 128; }
 
 hipError_t launch_wide(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images, hipStream_t stream,
-                       int in_layout, int out_layout, bool relu, int grid_cap, const ChipGeom &chip)
+                       int in_layout, int out_layout, bool relu, int grid_cap, const ChipGeom &chip, unsigned long long *deal)
 {
     using namespace xw;
     if (!wide_supported(g)) return hipErrorInvalidValue;
@@ -981,7 +1151,10 @@ hipError_t launch_wide(const LayerGeom &g, const sicn_weights &w, const uint8_t 
     int IW = g.IW, IH = g.IH, OW = g.OW, OH = g.OH, n_tiles = tiles_x * tiles_y, txs = tiles_x;
     uint32_t fl = flags;
     int n_xcd = chip.n_xcd;
-    void *args[] = {(void *)&in, (void *)&out, (void *)&ws, (void *)&w.d_bias, &IW, &IH, &OW, &OH, &txs, &n_tiles, &n_images, &in_layout, &out_layout, &fl, &n_xcd};
+    static_assert(DEAL_MAILBOX0 == WIDE_DEAL_MAX_XCDS, "the mailboxes start behind the XCDs' counters");
+    if (!wide_deal_pays(total, grid, chip)) deal = nullptr;   // few tiles per workgroup: all of them dealt statically (sicn_plan.h)
+    void *args[] = {(void *)&in, (void *)&out, (void *)&ws, (void *)&w.d_bias, &IW, &IH, &OW, &OH, &txs, &n_tiles, &n_images, &in_layout, &out_layout, &fl, &n_xcd,
+                    (void *)&deal};
     e = hipLaunchKernel(fn, dim3(grid), dim3(256), args, lds, stream);
     if (e != hipSuccess) return e;
     return hipGetLastError();

@@ -102,7 +102,7 @@ int chip_geom(ChipGeom *out)
 
 const DebugEnv &debug_env()
 {
-    static const DebugEnv d{env_int("SICN_MFMA_VARIANT"), env_int("SICN_DEBUG_KERNEL"), env_int("SICN_DEBUG_EXTRA_LDS")};
+    static const DebugEnv d{env_int("SICN_MFMA_VARIANT"), env_int("SICN_DEBUG_KERNEL"), env_int("SICN_DEBUG_EXTRA_LDS"), env_int("SICN_NO_DEAL")};
     return d;
 }
 }  // namespace sicn
@@ -564,11 +564,14 @@ static ChipGeom chip_or_default()
     return chip_geom(&c) == SICN_OK ? c : chip_from_cus(256);   // sizes can be asked for without a device: the whole MI355X
 }
 
+// round 5: the wide persistent kernels' tile deal (k_mfma16x.hip: DealX) — DEAL_WORDS zeroed words per layer, behind everything else
+static size_t deal_bytes(const sicn_net *net) { return align256(net->descs.size() * (size_t)DEAL_WORDS * sizeof(unsigned long long)); }
+
 extern "C" size_t sicn_net_workspace_bytes(const sicn_net *net, int n_images)
 {
     if (!net || n_images <= 0) return 0;
     const KsNeed ks = ksplit_need(net, n_images, chip_or_default());
-    return 2 * pingpong_slot_bytes(net, n_images) + KSPLIT_MAX * ks.partial + align256(ks.words * sizeof(unsigned long long));
+    return 2 * pingpong_slot_bytes(net, n_images) + KSPLIT_MAX * ks.partial + align256(ks.words * sizeof(unsigned long long)) + deal_bytes(net);
 }
 
 // Layer l's GDN / IGDN is applied by layer l + 1's kernel (k_l7g.hip) instead of k_gdn (sicn_options.gdn_fuse = 2): l + 1 is part of this call, takes the RGB
@@ -597,15 +600,16 @@ extern "C" int sicn_net_forward(const sicn_net *net, int first, int last, const 
     uint8_t *pp[2] = {(uint8_t *)workspace, (uint8_t *)workspace + slot};
     // K-split scratch: behind the ping-pong buffers when the workspace is of the size sicn_net_workspace_bytes asks for.  A smaller
     // (older-sized) or absent workspace only switches the automatic split off; a forced one (options.split_k > 1) is SICN_ENOSPC.
-    KSplitScratch ks_store{nullptr, 0, nullptr, 0, net->ks_tag};
+    KSplitScratch ks_store{nullptr, 0, nullptr, 0, net->ks_tag, nullptr};
     const KSplitScratch *ks = nullptr;
+    unsigned long long *deal_base = nullptr;   // the tile-deal words of this call's layers, zeroed below (a smaller / absent workspace: static deal)
     {
         ChipGeom chip;
         if (int rc = chip_geom(&chip)) return rc;
         const KsNeed need = ksplit_need(net, n_images, chip);
+        const size_t ks_total = 2 * slot + KSPLIT_MAX * need.partial + align256(need.words * sizeof(unsigned long long));
         if (need.partial) {
-            const size_t total = 2 * slot + KSPLIT_MAX * need.partial + align256(need.words * sizeof(unsigned long long));
-            if (workspace && workspace_bytes >= total) {
+            if (workspace && workspace_bytes >= ks_total) {
                 ks_store.partials = (uint8_t *)workspace + 2 * slot;
                 ks_store.partial_stride = need.partial;
                 ks_store.flags = (unsigned long long *)((uint8_t *)workspace + 2 * slot + KSPLIT_MAX * need.partial);
@@ -613,6 +617,18 @@ extern "C" int sicn_net_forward(const sicn_net *net, int first, int last, const 
                 ks = &ks_store;
             } else if (net->opt.split_k > 1)
                 return SICN_ENOSPC;
+        }
+        // does a layer of this call deal tiles dynamically?  (small inputs never do: no zeroing launch in front of them)
+        bool any_deal = false;
+        for (int l = first; l <= last && !any_deal; l++) {
+            const KernelKind k = pick_kernel(net->descs[l], net->opt);
+            any_deal = (k == KK_MFMA_CONV || k == KK_MFMA_DECONV) && plan_mfma(geom_of(net->descs[l]), n_images, net->opt, chip).deal;
+        }
+        if (any_deal && workspace && workspace_bytes >= ks_total + deal_bytes(net) && !debug_env().no_deal) {
+            deal_base = (unsigned long long *)((uint8_t *)workspace + ks_total);
+            // zeroed once per forward pass, by a kernel; every layer of the call gets its own DEAL_WORDS
+            if (launch_zero_words(deal_base, deal_bytes(net) / sizeof(unsigned long long), stream) != hipSuccess) return SICN_ENODEV;
+            ks = &ks_store;
         }
     }
     const uint8_t *cur = in;
@@ -641,6 +657,7 @@ extern "C" int sicn_net_forward(const sicn_net *net, int first, int last, const 
         // the activation of layer l moves into layer l + 1's kernel where that kernel exists (128 channels -> RGB, k_l7g) and nobody
         // else sees layer l's output: the activated tensor is then never written
         const bool defer = gdn_moves_to_next(net, l, last, tap_layer);
+        ks_store.deal = deal_base ? deal_base + (size_t)l * DEAL_WORDS : nullptr;
         int rc = run_layer(&net->descs[l], net->weights[l], cur, dst, n_images, stream, -1, net->opt, cur_layout, out_layout,
                            net->gdn[l], ks, defer, deferred);
         deferred = defer ? net->gdn[l] : nullptr;
@@ -757,6 +774,7 @@ extern "C" int sicn_debug_plan(const sicn_layer_desc *d, int n_images, const sic
         const MfmaPlan p = plan_mfma(g, n_images, o, chip);
         out[3] = p.family; out[4] = p.tile_x; out[5] = p.split_n; out[6] = p.split_k;
         out[7] = (int)p.grid_x; out[8] = (int)p.grid_y; out[9] = (int)p.grid_z;
+        out[10] = p.deal;
     } else if (k == KK_L7_RGB && o.gdn_fuse == 2) {   // as the layer runs behind a layer with an activation in a chain (k_l7g)
         const int tiles_x = (g.IW + L7G_PLAN_COLS - 1) / L7G_PLAN_COLS, steps_y = (g.IH + L7G_PLAN_ROWS - 1) / L7G_PLAN_ROWS;
         const int yc = l7g_chunks(tiles_x, n_images, steps_y, o.strip_chunks, 1, chip);

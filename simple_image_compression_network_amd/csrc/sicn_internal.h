@@ -63,7 +63,12 @@ struct KSplitScratch {
     unsigned long long *flags;  // [workgroups of the unsplit grid][KSPLIT_MAX]
     size_t n_flags;             // capacity in flag words
     unsigned long long nonce;
+    unsigned long long *deal;   // round 5: DEAL_WORDS zeroed words for the wide persistent kernels' tile deal (k_mfma16x.hip: DealX), or nullptr
 };
+// the tile deal of the wide persistent kernels: 16 ticket counters (one per XCD) + one mailbox per workgroup
+constexpr int DEAL_MAX_WORKGROUPS = WIDE_DEAL_MAX_WORKGROUPS;
+constexpr int DEAL_WORDS = WIDE_DEAL_MAX_XCDS + DEAL_MAX_WORKGROUPS;
+hipError_t launch_zero_words(unsigned long long *p, size_t words, hipStream_t stream);   // k_generic.hip
 constexpr int KSPLIT_MAX = 3;   // 192 input channels = 3 channel-group pairs
 
 // what plan_mfma (k_mfma16.hip) decides for a conv / deconv layer of the 128 / 192-channel shapes
@@ -73,6 +78,7 @@ struct MfmaPlan {
     int split_n;     // output-channel slices (workgroups of blockIdx.y), 1 = none
     int split_k;     // K slices (blockIdx.z), 1 = none
     unsigned grid_x, grid_y, grid_z;
+    int deal;        // family 2: 1 where the tile deal has its dynamic part (sicn_plan.h wide_deal_pays), given a workspace with room for it
 };
 MfmaPlan plan_mfma(const LayerGeom &g, int n_images, const sicn_options &o, const ChipGeom &chip);
 // does `ks` hold the partial tensors and flag words the plan's K split needs?
@@ -85,7 +91,7 @@ inline bool ksplit_scratch_fits(const LayerGeom &g, int n_images, const MfmaPlan
 // library defaults: zeros overridden by the SICN_* environment as it was at load time (read once)
 const sicn_options &default_options();
 // build-time experiment switches of k_mfma.hip (SICN_MFMA_VARIANT, SICN_DEBUG_KERNEL, SICN_DEBUG_EXTRA_LDS), read once
-struct DebugEnv { int mfma_variant, debug_kernel, extra_lds; };
+struct DebugEnv { int mfma_variant, debug_kernel, extra_lds, no_deal; };   // no_deal (SICN_NO_DEAL=1, read at load): the static tile deal even with a workspace (A/B)
 const DebugEnv &debug_env();
 
 // Geometry of the CURRENT device (hipGetDevice), read once per device from hipDeviceProp_t: SICN_OK, or SICN_ENODEV when there
@@ -110,7 +116,7 @@ bool wide_supported(const LayerGeom &g);
 size_t mfma16x_deconv_stream_bytes(int cin, int cout);   // 0 where the wide deconv does not exist
 void pack_mfma16x_deconv_stream(const int8_t *w_okc, int cin, int cout, int8_t *dst);
 hipError_t launch_wide(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images, hipStream_t stream,
-                       int in_layout, int out_layout, bool relu, int grid_cap, const ChipGeom &chip);
+                       int in_layout, int out_layout, bool relu, int grid_cap, const ChipGeom &chip, unsigned long long *deal = nullptr);
 // k_mfma16p.hip: the software-pipelined conv / deconv kernels (tile_x = 16 | 32)
 bool pipelined_supported(const LayerGeom &g, int tile_x);
 hipError_t launch_pipelined(const LayerGeom &g, const sicn_weights &w, const uint8_t *in, uint8_t *out, int n_images,

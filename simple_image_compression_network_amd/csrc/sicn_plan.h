@@ -50,6 +50,15 @@ inline unsigned wide_grid(long total_tiles, int grid_cap, const ChipGeom &c)
     const long need = (total_tiles + c.n_xcd - 1) / c.n_xcd * c.n_xcd;
     return (unsigned)(need < cap ? need : cap);
 }
+// the dynamic part of the wide kernels' tile deal (k_mfma16x.hip DealX: one ticket counter per XCD + one mailbox per workgroup in the call's
+// workspace).  It pays where a workgroup walks many tiles (measured r05 on 256 CUs: 32 tiles each in layers 1 / 6 of 8 x 4K, - 13 and - 9 us);
+// with 8 (layers 2 / 5) one tile is 12 % of a workgroup's work, nothing can be balanced and the look at the other XCDs' counters at the end
+// only costs (+ 3 us): static there
+constexpr int WIDE_DEAL_MAX_XCDS = 16, WIDE_DEAL_MAX_WORKGROUPS = 512, WIDE_DEAL_MIN_TILES_PER_WORKGROUP = 16;
+inline bool wide_deal_pays(long total_tiles, unsigned grid, const ChipGeom &c)
+{
+    return grid <= (unsigned)WIDE_DEAL_MAX_WORKGROUPS && c.n_xcd <= WIDE_DEAL_MAX_XCDS && total_tiles >= (long)WIDE_DEAL_MIN_TILES_PER_WORKGROUP * grid;
+}
 // automatic choice of the wide form: from WIDE_MIN_TILES_PER_CU tiles (16 x 32) per CU on; the conv already from 3.5 rounds
 // when the last round is at least 90 % full (measured r03 on 256 CUs: 1020 tiles 131 - 140 us against 144 - 149)
 inline bool wide_automatic(long tiles_w, bool deconv, const ChipGeom &c)

@@ -133,6 +133,9 @@ def test_launch_planning_follows_the_chip_size_without_gpu():
         for l in (1, 2, 5, 6):
             p = _plan(d4k[l], 8, n_cu)
             assert p["family"] == 2 and p["gx"] == n_cu, (n_cu, l, p)
+        # ... and part of the tiles dealt dynamically across the XCDs only where a workgroup walks >= 16 of them (32 in layers 1 / 6, 8 in 2 / 5
+        # on the whole chip, 64 and 15.9 on half of it; every layer of a 32-CU partition; the slot is "chunks" for the other kinds)
+        assert [_plan(d4k[l], 8, n_cu)["chunks"] for l in (1, 2, 5, 6)] == {256: [1, 0, 0, 1], 128: [1, 0, 0, 1], 32: [1, 1, 1, 1]}[n_cu]
         p7 = _plan(d4k[7], 8, n_cu)                     # 60 strips x 8 images = 480 workgroups: never cut, grid padded to the XCD count
         assert p7["chunks"] == 1 and p7["gx"] % p7["n_xcd"] == 0 and p7["gx"] == 480
     # one 1080p image: the wide conv needs >= 3.5 full rounds of the CUs -> not on 256, but on a 32-CU partition

@@ -292,6 +292,44 @@ def test_k_split_in_chain(api, size):
         assert _sha(latent[0].cpu().numpy()) == HASHES["layers"][name][3]
 
 
+@pytest.mark.parametrize("grid", [8, 16, 24])
+@pytest.mark.parametrize("case", [(128, 128, 8, 16, 512, 200, 0), (128, 128, 8, 16, 250, 104, 1)])
+def test_wide_kernels_dynamic_tile_deal_matches_oracle(api, case, grid):
+    """Round 5: inside a net (whose workspace carries the deal area) a wide persistent workgroup takes its tiles beyond the first two from
+    ticket counters — its own XCD's, then the other XCDs' (k_mfma16x.hip: DealX).  Forced onto few workgroups (1 / 2 / 3 per XCD) that
+    walk >= 16 tiles each, so that ranges run dry at different times and tickets are taken from other XCDs: every tile must be computed
+    exactly once (any lost or doubled tile shows in the bytes), on repeated calls (the deal area is re-zeroed by every forward pass) and
+    in a captured graph (the zeroing is a node of it); against the oracle and against the static deal (a layer call without a net)."""
+    rng = np.random.default_rng(abs(hash(case)) % (1 << 31) + grid)
+    d = _mk_desc(*case)
+    W, b, words = _rand_params(rng, d)
+    x = rng.integers(0, 128, (3,) + d.in_shape, dtype=np.uint8)
+    x[1].reshape(-1)[::7] |= 0x80
+    fpw = api.FixedPointWeights(d.SIMD, 4, d.PE, d.W_TILES, words)
+    net = api.EightLayersNet(descs=[d], params=[(fpw, b)], options={"wave_tile": 128, "persistent_grid": grid})
+    xin = _dev(x)
+    ref_fn = sicn_ref.deconv522_ref if d.transposed else sicn_ref.conv2d_ref
+    ref = np.stack([ref_fn(x[i], W, b) for i in range(3)])
+    for _ in range(3):
+        out, _ = net.run_layers(0, 0, xin)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), ref)
+    static = _run_layer(api, d, words, b, x, wave_tile=128, persistent_grid=grid)      # no workspace: the static deal
+    assert np.array_equal(static, ref)
+    out = torch.zeros_like(out)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            net.run_layers(0, 0, xin, out=out)
+    for _ in range(3):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), ref)
+
+
 PERSISTENT_CASES = [(128, 128, 8, 16, 130, 66, 0), (128, 128, 8, 16, 66, 18, 0), (128, 128, 8, 16, 7, 5, 0), (128, 128, 4, 32, 131, 33, 0),
                     (128, 128, 8, 16, 200, 90, 0), (128, 128, 8, 16, 64, 16, 0)]
 
