@@ -12,7 +12,10 @@ chained by `sicn_net` — plus this project's own fixed-point GDN (include/sicn_
                                 checkerboard — from the already decoded anchor neighbours)
     main synthesis  g_s : y  -> x^   L4..L7, IGDN after L4, L5, L6
 
-Encoder and decoder both derive s from the DECODED z, so the model the two sides use is identical by construction.
+The decoder derives s from the decoded z, the encoder from z itself: the z coder is lossless over bytes, so the two are the same tensor
+whenever the container fits its slot (and when it does not, the encoder's status says so and nothing downstream is valid anyway).
+`HyperpriorCodec(verify_z=True)` makes the encoder decode its own z container first and use THAT (rounds 2 - 4 always did; it is a
+self-check of the coder inside every encode, 0.05 ms of an 8 x 4K step, not something the format needs).
 All of it is kernel launches on one stream: no host synchronisation between the stages (verdicts stay on the device until
 `check()`), so a whole encode + decode can be enqueued back to back or captured in a hipGraph.
 
@@ -94,9 +97,10 @@ def hyper_parameters(width: int, height: int, seed: int = 0, use_gdn: bool = Tru
 
 class HyperpriorCodec:
     def __init__(self, width: int, height: int, n_images: int, seed: int = 0, device="cuda", use_gdn: bool = True,
-                 main_params=None, options=None, z_stream_symbols=None):
+                 main_params=None, options=None, z_stream_symbols=None, verify_z: bool = False):
         import torch
         self.n, self.width, self.height = int(n_images), int(width), int(height)
+        self.verify_z = bool(verify_z)
         self.device = torch.device(device)
         hp = hyper_parameters(width, height, seed, use_gdn)
         self.gdn_np = hp["gdn_np"]
@@ -141,9 +145,11 @@ class HyperpriorCodec:
         self.main.analysis(x, self.y)
         self.h_a.run_layers(0, 1, self.y, out=self.z)
         self.z_coder.encode(self.z)
-        # the model must be the one the decoder can rebuild: derive the scale map from the DECODED hyper-latent
-        self.z_coder.decode(self.z_hat)
-        self.y_coder.encode(self.y, self._scale_map(self.z_hat))
+        # the model must be the one the decoder can rebuild: h_s of the hyper-latent the container holds — which IS z (lossless coder);
+        # verify_z decodes the container to prove it on every call
+        if self.verify_z:
+            self.z_coder.decode(self.z_hat)
+        self.y_coder.encode(self.y, self._scale_map(self.z_hat if self.verify_z else self.z))
         return self.z_coder.slots, self.y_coder.slots
 
     def decode(self, out, z_slots=None, y_slots=None, z_valid=None, y_valid=None):

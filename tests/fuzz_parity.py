@@ -22,6 +22,9 @@ ap.add_argument("--big", action="store_true", help="image sizes up to 600 x 400 
 ap.add_argument("--chains", type=int, default=0, help="additionally: whole 8-layer chains (internal layouts) on random sizes")
 ap.add_argument("--gdn", type=int, default=0, help="additionally: layer 0 + GDN in one kernel (k_l0g) and (layer + GDN) -> RGB layer chains with the "
                 "activation applied by the RGB layer (k_l7g), random sizes, against the C oracle of the GDN")
+ap.add_argument("--deal", type=int, default=0, help="additionally: one-layer nets of conv / deconv 128 -> 128 on few wide persistent workgroups that walk >= 16 "
+                "tiles each, so that the dynamic part of the tile deal (k_mfma16x.hip DealX: tickets, stealing across XCDs) is what runs; three "
+                "calls + a graph replay each")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 
@@ -167,4 +170,54 @@ for case in range(args.gdn):
         print(f"gdn {case}: ok ({what} n={n} inverse={inverse} {env})", flush=True)
 if args.gdn:
     print(f"{args.gdn - gbad}/{args.gdn} fused-activation cases bit-exact")
-sys.exit(1 if (bad or cbad or gbad) else 0)
+# the wide kernels' dynamic tile deal: every tile exactly once, whoever takes it
+dbad = 0
+if args.deal:
+    from oracle import c_oracle  # noqa: E402,F811  (checker)
+for case in range(args.deal):
+    tr = int(rng.integers(2))
+    grid = int(rng.choice([8, 16]))
+    # position grid (output for the conv, input for the deconv) of tx x ty tiles of 16 x 32, ragged at both edges, with >= 16 tiles per workgroup
+    n = int(rng.integers(1, 4))
+    need = (16 * grid + n - 1) // n                      # tiles per image
+    tx = int(rng.integers(2, 12))
+    ty = max(1, (need + tx - 1) // tx + int(rng.integers(0, 3)))
+    mw, mh = 32 * (tx - 1) + int(rng.integers(1, 33)), 16 * (ty - 1) + int(rng.integers(1, 17))
+    assert ((mw + 31) // 32) * ((mh + 15) // 16) * n >= 16 * grid
+    w, h = (mw, mh) if tr else (2 * mw - int(rng.integers(2)), 2 * mh - int(rng.integers(2)))
+    ow, oh = (2 * w, 2 * h) if tr else ((w + 1) // 2, (h + 1) // 2)
+    d = LayerDesc(IFM_CH=128, IFM_ROW=w, IFM_COL=h, OFM_CH=128, OFM_ROW=ow, OFM_COL=oh, SIMD=8, PE=16, W_TILES=8 * 400, transposed=tr)
+    d.validate()
+    Wt = rng.integers(-8, 8, (128, 5, 5, 128)).astype(np.int8)
+    bt = rng.integers(-128, 128, 128).astype(np.int8)
+    fpw = api.FixedPointWeights(8, 4, 16, d.W_TILES, sicn_ref.pack_finn_tiles(Wt, 8, 16))
+    net = api.EightLayersNet(descs=[d], params=[(fpw, api.FixedPointWeights(1, 8, 1, 128, bt.view(np.uint8).astype(np.uint64)))],
+                             options={"wave_tile": 128, "persistent_grid": grid})
+    x = rng.integers(0, 128, (n,) + d.in_shape, dtype=np.uint8)
+    xin = torch.from_numpy(x).cuda()
+    words = sicn_ref.pack_finn_tiles(Wt, 8, 16)
+    ref = np.stack([c_oracle.run_layer(d, words, bt, x[i], form="direct", threads=os.cpu_count() or 1) for i in range(n)])   # the C closed form: these are big
+    ok = True
+    out = None
+    for _ in range(3):
+        out, _ = net.run_layers(0, 0, xin)
+        torch.cuda.synchronize()
+        ok = ok and np.array_equal(out.cpu().numpy(), ref)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            net.run_layers(0, 0, xin, out=out)
+    for _ in range(2):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        ok = ok and np.array_equal(out.cpu().numpy(), ref)
+    if not ok:
+        dbad += 1
+        print(f"DEAL MISMATCH {case}: tr={tr} {w}x{h} n={n} grid={grid}", flush=True)
+    else:
+        print(f"deal {case}: ok ({'deconv' if tr else 'conv'} {w}x{h} n={n}, {grid} workgroups)", flush=True)
+if args.deal:
+    print(f"{args.deal - dbad}/{args.deal} dynamic-deal cases bit-exact")
+sys.exit(1 if (bad or cbad or gbad or dbad) else 0)

@@ -88,7 +88,7 @@ def test_gpu_hyperprior_decoder_needs_only_the_containers():
     """A second codec object (same seed = same weights) decodes from the two container sets alone."""
     import torch
     from simple_image_compression_network_amd.hyperprior import HyperpriorCodec
-    enc = HyperpriorCodec(128, 96, 1, seed=3)
+    enc = HyperpriorCodec(128, 96, 1, seed=3, verify_z=True)   # the encoder that decodes its own z container first
     dec = HyperpriorCodec(128, 96, 1, seed=3)
     x = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (1, 96, 128, 3), dtype=np.uint8)).cuda()
     zc, yc = enc.encode(x)
