@@ -48,7 +48,7 @@ PEAK_INT8_TOPS = 5000.0   # dense int8 MFMA = 2x the ~2.5 PFLOP/s bf16 dense pea
 PEAK_HBM_GBS = 8000.0     # HBM3E spec
 NOMINAL_SCLK_MHZ = 2400.0  # the shader clock the nominal MFMA peak is quoted at
 KERNEL_SOURCES = ("k_common.hpp", "k_l0_common.hpp", "k_mfma16.hip", "k_mfma16p.hip", "k_mfma16x.hip", "k_mfma.hip", "k_rgb.hip", "k_generic.hip", "sicn_plan.h",
-                  "sicn_abi.hip")   # what the eight layers of the headline run through (kernels + every launch decision)
+                  "sicn_internal.h", "sicn_abi.hip")   # what the eight layers of the headline run through (kernels + every launch decision)
 
 
 # what the secondary legs (with_coder, hyperprior) run through on top of that: the coders and the activation (the
