@@ -53,11 +53,13 @@ def timed(fn):
 
 t_serial = timed(serial)
 ref = outs[0].clone()
-se, sd = torch.cuda.Stream(), torch.cuda.Stream()
+# optional: stream priorities of the encode / decode side (-1 = high), e.g. "hyper_pipelined.py 12 0 -1"
+pe, pd = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (0, 0)
+se, sd = torch.cuda.Stream(priority=pe), torch.cuda.Stream(priority=pd)
 t_pipe = timed(lambda k: pipelined(k, se, sd))
 for hc in codecs:
     hc.check()
 ok = bool(torch.equal(outs[0], ref)) and bool(torch.equal(outs[1], ref))
-print(f"hyperprior 8 x 4K: one stream {t_serial:.3f} ms per step; encode(k+1) beside decode(k) on two streams {t_pipe:.3f} ms per step; outputs equal {ok}")
+print(f"hyperprior 8 x 4K: one stream {t_serial:.3f} ms per step; encode(k+1) beside decode(k) on two streams (priorities {pe} / {pd}) {t_pipe:.3f} ms per step; outputs equal {ok}")
 t_serial2 = timed(serial)
 print(f"one stream again {t_serial2:.3f} ms")
