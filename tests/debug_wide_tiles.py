@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where does the wide deconv / conv differ from the oracle? usage: x_debug.py W H transposed [grid]"""
+"""(checker-side debugging aid: lives under tests/ because it imports the oracle.) Where does the wide deconv / conv differ from the oracle? usage: tests/debug_wide_tiles.py W H transposed [grid]"""
 import sys
 from pathlib import Path
 import numpy as np
