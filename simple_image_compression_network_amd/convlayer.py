@@ -17,7 +17,7 @@ import numpy as np
 from . import _lib
 from .api import FixedPointWeights, _stream_ptr
 
-__all__ = ["ConvLayerDesc", "PassThroughActivation", "ThresholdsActivation", "ConvLayer_Batch"]
+__all__ = ["ConvLayerDesc", "PassThroughActivation", "ThresholdsActivation", "ConvLayer", "ConvLayer_Batch"]
 
 
 @dataclass(frozen=True)
@@ -68,43 +68,79 @@ class ConvLayerDesc:
                                    ACT_VAL=int(activation.ACT_VAL) if th else 0)
 
 
+class ConvLayer:
+    """A layer with its parameters resident on the device: descriptor, weights and activation are validated and uploaded ONCE (the reference's
+    weights and thresholds are objects the caller builds once and passes by reference, convlayer.h:89-111), every call only enqueues.
+    `layer(in_, out=None, reps=1, stream=None, kernel=0)` — tensors as for ConvLayer_Batch.  `close()` (or garbage collection) frees the handle;
+    the caller keeps it alive until the last enqueued call has run."""
+
+    def __init__(self, desc: ConvLayerDesc, weights: FixedPointWeights, activation):
+        L = _lib.lib()
+        self.desc, self.activation = desc, activation
+        self._cd = desc.to_c(activation)
+        _lib.check(L.sicn_convlayer_validate(ctypes.byref(self._cd)), "sicn_convlayer_validate")
+        words = np.ascontiguousarray(weights.m_weights, dtype=np.uint64)
+        if words.shape != (desc.PE, desc.W_TILES):
+            raise ValueError("FixedPointWeights fold does not match the layer")
+        thr = None
+        if isinstance(activation, ThresholdsActivation):
+            thr = np.ascontiguousarray(activation.m_thresholds, dtype=np.int32)
+            if thr.shape[:2] != (desc.PE, desc.OFM_CH // desc.PE):
+                raise ValueError("m_thresholds must be [PE][NF][NumTH]")
+        self._h = ctypes.c_void_p()
+        _lib.check(L.sicn_convlayer_params_create(ctypes.byref(self._cd), words.ctypes.data_as(ctypes.c_void_p), 8,
+                                                  thr.ctypes.data_as(ctypes.c_void_p) if thr is not None else None,
+                                                  ctypes.byref(self._h)), "sicn_convlayer_params_create")
+
+    def shapes(self, reps: int):
+        import torch
+        d = self.desc
+        dt = {2: torch.uint8, 4: torch.uint8, 8: torch.uint8, 16: torch.int16, 32: torch.int32}[d.OUT_BIT]
+        return ((reps, d.IFM_DIM, d.IFM_DIM, d.IFM_CH * d.IN_BIT // 8),
+                (reps, d.OFM_DIM, d.OFM_DIM, d.OFM_CH * d.OUT_BIT // 8 if d.OUT_BIT < 8 else d.OFM_CH), dt)
+
+    def __call__(self, in_, out=None, reps: int = 1, stream=None, kernel: int = 0):
+        import torch
+        if not self._h:
+            raise RuntimeError("ConvLayer is closed")
+        shape_in, shape_out, dt = self.shapes(reps)
+        if not (in_.is_cuda and in_.dtype == torch.uint8 and in_.is_contiguous() and tuple(in_.shape) == shape_in):
+            raise TypeError(f"in: need a contiguous CUDA uint8 tensor of shape {shape_in}")
+        if out is None:
+            out = torch.empty(shape_out, dtype=dt, device=in_.device)
+        if not (out.is_cuda and out.dtype == dt and out.is_contiguous() and tuple(out.shape) == shape_out):
+            raise TypeError(f"out: need a contiguous CUDA {dt} tensor of shape {shape_out}")
+        _lib.check(_lib.lib().sicn_conv_layer_batch_kernel(ctypes.byref(self._cd), self._h, ctypes.c_void_p(in_.data_ptr()),
+                                                           ctypes.c_void_p(out.data_ptr()), reps, int(kernel), _stream_ptr(stream)),
+                   "sicn_conv_layer_batch_kernel")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            try:
+                if _lib._lib is not None:
+                    _lib._lib.sicn_convlayer_params_free(self._h)
+            except Exception:   # interpreter shutdown
+                pass
+            self._h = None
+
+    __del__ = close
+
+
 def ConvLayer_Batch(desc: ConvLayerDesc, in_, out, weights: FixedPointWeights, activation, reps: int = 1, stream=None,
                     kernel: int = 0):
     """in_: CUDA uint8 [reps][IFM_DIM][IFM_DIM][IFM_CH * IN_BIT / 8] — the stream words of the pixels, lane c in bits [c IN_BIT, (c + 1) IN_BIT)
     (one byte per lane at IN_BIT = 8); out: CUDA tensor [reps][OFM_DIM][OFM_DIM][OFM_CH] of dtype uint8 / int16 / int32 matching OUT_BIT
     (8 / 16 / 32), or uint8 [reps][OFM_DIM][OFM_DIM][OFM_CH * OUT_BIT / 8] for OUT_BIT 2 / 4 (packed exactly like an input stream, so it
     can be handed to the next layer as it is), or None to allocate.  Returns `out`.
-    kernel: 0 = automatic (MFMA kernel when the shape allows), 1 = the direct kernel (tests compare the two)."""
+    kernel: 0 = automatic (MFMA kernel when the shape allows), 1 = the direct kernel (tests compare the two).
+    The reference's calling convention: parameters travel with every call (uploaded, used, freed; the call returns when the layer has run).
+    `ConvLayer` keeps them resident."""
     import torch
-    L = _lib.lib()
-    cd = desc.to_c(activation)
-    _lib.check(L.sicn_convlayer_validate(ctypes.byref(cd)), "sicn_convlayer_validate")
-    words = np.ascontiguousarray(weights.m_weights, dtype=np.uint64)
-    if words.shape != (desc.PE, desc.W_TILES):
-        raise ValueError("FixedPointWeights fold does not match the layer")
-    thr = None
-    if isinstance(activation, ThresholdsActivation):
-        thr = np.ascontiguousarray(activation.m_thresholds, dtype=np.int32)
-        if thr.shape[:2] != (desc.PE, desc.OFM_CH // desc.PE):
-            raise ValueError("m_thresholds must be [PE][NF][NumTH]")
-    dt = {2: torch.uint8, 4: torch.uint8, 8: torch.uint8, 16: torch.int16, 32: torch.int32}[desc.OUT_BIT]
-    shape_in = (reps, desc.IFM_DIM, desc.IFM_DIM, desc.IFM_CH * desc.IN_BIT // 8)
-    shape_out = (reps, desc.OFM_DIM, desc.OFM_DIM, desc.OFM_CH * desc.OUT_BIT // 8 if desc.OUT_BIT < 8 else desc.OFM_CH)
-    if not (in_.is_cuda and in_.dtype == torch.uint8 and in_.is_contiguous() and tuple(in_.shape) == shape_in):
-        raise TypeError(f"in: need a contiguous CUDA uint8 tensor of shape {shape_in}")
-    if out is None:
-        out = torch.empty(shape_out, dtype=dt, device=in_.device)
-    if not (out.is_cuda and out.dtype == dt and out.is_contiguous() and tuple(out.shape) == shape_out):
-        raise TypeError(f"out: need a contiguous CUDA {dt} tensor of shape {shape_out}")
-    h = ctypes.c_void_p()
-    _lib.check(L.sicn_convlayer_params_create(ctypes.byref(cd), words.ctypes.data_as(ctypes.c_void_p), 8,
-                                              thr.ctypes.data_as(ctypes.c_void_p) if thr is not None else None,
-                                              ctypes.byref(h)), "sicn_convlayer_params_create")
+    layer = ConvLayer(desc, weights, activation)
     try:
-        _lib.check(L.sicn_conv_layer_batch_kernel(ctypes.byref(cd), h, ctypes.c_void_p(in_.data_ptr()),
-                                                  ctypes.c_void_p(out.data_ptr()), reps, int(kernel), _stream_ptr(stream)),
-                   "sicn_conv_layer_batch_kernel")
-        torch.cuda.current_stream().synchronize()     # the parameter handle is freed below
+        out = layer(in_, out, reps, stream, kernel)
+        (stream if stream is not None and hasattr(stream, "synchronize") else torch.cuda.current_stream()).synchronize()   # the handle is freed below
     finally:
-        L.sicn_convlayer_params_free(h)
+        layer.close()
     return out

@@ -131,6 +131,36 @@ def test_gpu_mfma_and_direct_kernels_agree():
     assert np.array_equal(a[1].cpu().numpy().astype(np.int64) & 0xFFFFFFFF, ref.astype(np.int64))
 
 
+@pytest.mark.gpu
+def test_gpu_resident_conv_layer_equals_the_per_call_form():
+    """ConvLayer keeps descriptor, weights and thresholds on the device; repeated calls (no synchronisation in between, a second stream)
+    give what ConvLayer_Batch — upload, run, free per call: the reference's calling convention — gives."""
+    import torch
+    from simple_image_compression_network_amd.api import FixedPointWeights
+    from simple_image_compression_network_amd.convlayer import ConvLayer, ConvLayer_Batch, ConvLayerDesc, ThresholdsActivation
+    rng = np.random.default_rng(5)
+    K, C, D, O = 3, 32, 20, 16
+    w = rng.integers(-2, 2, (O, K * K * C)).astype(np.int8)
+    words = sicn_ref.pack_finn_tiles_generic(w, 8, 8, 2)
+    desc = ConvLayerDesc(K=K, IFM_CH=C, IFM_DIM=D, OFM_CH=O, SIMD=8, PE=8, W_BIT=2, IN_SIGNED=False, OUT_BIT=8)
+    thr = np.sort(rng.integers(-3000, 3000, (8, O // 8, 7)), axis=2).astype(np.int32)
+    act = ThresholdsActivation(ACC_BIT=16, ACC_SIGNED=True, m_thresholds=thr, ACT_VAL=0)
+    fpw = FixedPointWeights(8, 2, 8, desc.W_TILES, words)
+    xs = [torch.from_numpy(rng.integers(0, 256, (2, D, D, C), dtype=np.uint8)).cuda() for _ in range(3)]
+    want = [ConvLayer_Batch(desc, x, None, fpw, act, 2).clone() for x in xs]
+    layer = ConvLayer(desc, fpw, act)
+    got = [layer(x, None, 2) for x in xs]                  # three launches back to back, one handle
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        again = layer(xs[1], None, 2, stream=side)
+    torch.cuda.synchronize()
+    assert all(torch.equal(g, w_) for g, w_ in zip(got, want)) and torch.equal(again, want[1])
+    layer.close()
+    with pytest.raises(RuntimeError):
+        layer(xs[0], None, 2)
+
+
 # ---- sub-byte lanes (round 5, VERDICT r4 item 8): the streams carry IFM_CH * IN_BIT / OFM_CH * OUT_BIT bits per pixel -------------------
 # (K, C, D, O, SIMD, PE, W_BIT, IN_BIT, IN_SIGNED, ACC_BIT, ACC_SIGNED, OUT_BIT, NUM_TH, ACT_VAL)
 PACKED_CASES = [

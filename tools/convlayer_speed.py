@@ -30,4 +30,17 @@ for (K, C, D, O, reps) in [(3, 64, 130, 64, 4), (5, 128, 68, 128, 4), (1, 256, 6
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
     macs = reps * desc.OFM_DIM ** 2 * O * K * K * C
-    print(f"K={K} C={C} D={D} O={O} reps={reps}: {dt * 1e3:.3f} ms  {2 * macs / dt / 1e12:.2f} TOP/s")
+    # the same with the parameters resident (cl.ConvLayer): what the kernel itself takes (events around 20 launches)
+    layer = cl.ConvLayer(desc, fpw, act)
+    layer(x, out, reps)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        layer(x, out, reps)
+    e1.record()
+    torch.cuda.synchronize()
+    dk = e0.elapsed_time(e1) / 20 * 1e-3
+    layer.close()
+    print(f"K={K} C={C} D={D} O={O} reps={reps}: per call with upload {dt * 1e3:.3f} ms ({2 * macs / dt / 1e12:.2f} TOP/s); parameters resident "
+          f"{dk * 1e6:.1f} us ({2 * macs / dk / 1e12:.1f} TOP/s)")
