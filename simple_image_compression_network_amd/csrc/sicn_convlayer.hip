@@ -144,27 +144,47 @@ __global__ __launch_bounds__(256) void k_convlayer_mfma(const uint8_t *__restric
         for (int c = 0; c < 4; c++) acc[c][j] = b;
     }
     const uint32_t flip = d.IN_SIGNED ? 0u : 0x80808080u;
-    for (int t = 0; t < KK; t++) {
-        const int ky = t / K, kx = t - ky * K;
-        const uint32_t tap = (uint32_t)((ky * D + kx) * C);
-        for (int cc = 0; cc < nchunk; cc++) {
-            const int c0 = cc * 64 + 16 * g;              // this lane's 16 channel bytes of the K step
-            const bool valid = c0 < C;                     // C % 16 == 0: a 16-byte group is all in or all out (weights 0)
-            v4i_t bf[4], af[4];
+    // K walk: step s = (tap t, 64-channel chunk cc), t outer.  The operands of step s + 1 are requested before the 16 MFMAs of step s
+    // (round 5: the loop used to load, wait and multiply — one exposed memory round trip per step; two register sets, the loop unrolled by two)
+    const int nstep = KK * nchunk;
+    int t_n = 0, cc_n = 0, ky_n = 0, kx_n = 0;            // the step the next request is for
+    auto request = [&](v4i_t (&bf)[4], v4i_t (&af)[4]) {
+        const uint32_t tap = (uint32_t)((ky_n * D + kx_n) * C);
+        const int c0 = cc_n * 64 + 16 * g;                // this lane's 16 channel bytes of the K step
+        const bool valid = c0 < C;                         // C % 16 == 0: a 16-byte group is all in or all out (weights 0)
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const uint4 q = *reinterpret_cast<const uint4 *>(img + pix[c] + tap + (valid ? c0 : 0));
-                bf[c] = v4i_t{(int)(q.x ^ flip), (int)(q.y ^ flip), (int)(q.z ^ flip), (int)(q.w ^ flip)};
+        for (int c = 0; c < 4; c++) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(img + pix[c] + tap + (valid ? c0 : 0));
+            bf[c] = v4i_t{(int)(q.x ^ flip), (int)(q.y ^ flip), (int)(q.z ^ flip), (int)(q.w ^ flip)};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int jj = j0 + j < ntile ? j0 + j : ntile - 1;
+            af[j] = *reinterpret_cast<const v4i_t *>(wm + ((((size_t)jj * KK + t_n) * nchunk + cc_n) * 16 + col) * 64 + 16 * g);
+        }
+        if (++cc_n == nchunk) {
+            cc_n = 0;
+            t_n++;
+            if (++kx_n == K) {
+                kx_n = 0;
+                ky_n++;
             }
+        }
+    };
+    auto multiply = [&](const v4i_t (&bf)[4], const v4i_t (&af)[4]) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int jj = j0 + j < ntile ? j0 + j : ntile - 1;
-                af[j] = *reinterpret_cast<const v4i_t *>(wm + ((((size_t)jj * KK + t) * nchunk + cc) * 16 + col) * 64 + 16 * g);
-            }
+        for (int j = 0; j < 4; j++)
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int c = 0; c < 4; c++) acc[c][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[j], bf[c], acc[c][j], 0, 0, 0);
+            for (int c = 0; c < 4; c++) acc[c][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[j], bf[c], acc[c][j], 0, 0, 0);
+    };
+    v4i_t bf0[4], af0[4], bf1[4], af1[4];
+    request(bf0, af0);
+    for (int s_ = 0; s_ < nstep; s_ += 2) {
+        if (s_ + 1 < nstep) request(bf1, af1);
+        multiply(bf0, af0);
+        if (s_ + 1 < nstep) {
+            if (s_ + 2 < nstep) request(bf0, af0);
+            multiply(bf1, af1);
         }
     }
     // epilogue: lane holds, per (column tile c, weight tile j), channels 16(j0+j) + 4g .. +3 of position p0 + 16c + col
