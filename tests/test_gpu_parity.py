@@ -330,6 +330,31 @@ def test_wide_kernels_dynamic_tile_deal_matches_oracle(api, case, grid):
         assert np.array_equal(out.cpu().numpy(), ref)
 
 
+def test_wide_kernels_fall_back_to_the_static_deal_in_a_workspace_of_the_old_size(api):
+    """include/sicn.h: a workspace without room for the deal words (a size computed by library 0.2: 528 eight-byte words per layer less) is
+    not an error — the wide kernels then deal every tile statically.  Same bytes either way."""
+    import ctypes
+    L = api._lib.lib()
+    rng = np.random.default_rng(91)
+    d = _mk_desc(128, 128, 8, 16, 250, 104, 1)           # 8 x 7 tiles x 3 images on 8 workgroups: 21 each, the deal's dynamic part is on
+    W, b, words = _rand_params(rng, d)
+    x = rng.integers(0, 128, (3,) + d.in_shape, dtype=np.uint8)
+    fpw = api.FixedPointWeights(d.SIMD, 4, d.PE, d.W_TILES, words)
+    net = api.EightLayersNet(descs=[d], params=[(fpw, b)], options={"wave_tile": 128, "persistent_grid": 8})
+    xin = _dev(x)
+    full = int(L.sicn_net_workspace_bytes(net._h, 3))
+    small = full - (528 * 8 + 255) // 256 * 256          # one layer's deal words, as sicn_abi.hip aligns them
+    assert small >= 0                                     # (a one-layer net needs nothing else: 0 bytes then)
+    ref = np.stack([sicn_ref.deconv522_ref(x[i], W, b) for i in range(3)])
+    for nbytes in (full, small):
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device="cuda")
+        out = torch.zeros((3,) + d.out_shape, dtype=torch.uint8, device="cuda")
+        rc = L.sicn_net_forward(net._h, 0, 0, ctypes.c_void_p(xin.data_ptr()), ctypes.c_void_p(out.data_ptr()), -1, None, 3,
+                                ctypes.c_void_p(ws.data_ptr()), nbytes, api._stream_ptr(None))
+        torch.cuda.synchronize()
+        assert rc == 0 and np.array_equal(out.cpu().numpy(), ref), nbytes
+
+
 PERSISTENT_CASES = [(128, 128, 8, 16, 130, 66, 0), (128, 128, 8, 16, 66, 18, 0), (128, 128, 8, 16, 7, 5, 0), (128, 128, 4, 32, 131, 33, 0),
                     (128, 128, 8, 16, 200, 90, 0), (128, 128, 8, 16, 64, 16, 0)]
 
